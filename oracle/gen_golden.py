@@ -1,0 +1,232 @@
+"""Golden-vector generator.  Runs ONLY in the build container, where /root/reference is importable.
+
+    mkdir -p /tmp/golden_cwd && cd /tmp/golden_cwd && \
+    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|parts]
+
+It imports the reference's own ``src.modeling.meta_arch`` / ``src.modeling.moe`` modules (SURVEY.md
+§8c, Appendix C), replaces only the two hub-NAME loaders by local random-weight construction of the
+same HF classes, loads the deterministic weights of ``oracle/det_weights.py``, runs the reference in
+``eval()`` with autograd enabled and writes inputs-free fixtures (expected outputs + gradients) to
+``tests/golden/*.npz``.  Weights and inputs are NOT stored: they are regenerated bit-identically from
+names/shapes/seeds recorded in the fixture's ``meta`` JSON.  Nothing from the reference is copied.
+"""
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import det_weights as dw  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+TINY = dict(D=64, vit_heads=4, vit_layers=2, vit_inter=128, image=48, patch=16,
+            vocab=120, txt_heads=4, txt_layers=2, txt_inter=128, max_pos=20, seq=8,
+            fusion_heads=4, fusion_layers=2, moe_hidden=128, num_answers=37, answer_hidden=[48, 40], batch=3)
+FULL = dict(D=768, vit_heads=12, vit_layers=12, vit_inter=3072, image=224, patch=32,
+            vocab=64001, txt_heads=12, txt_layers=12, txt_inter=3072, max_pos=258, seq=64,
+            fusion_heads=8, fusion_layers=2, moe_hidden=2048, num_answers=3000, answer_hidden=[768, 512], batch=8)
+
+
+def build_reference_model(dims, fusion_type, num_experts, pooling='cls'):
+    from transformers import CLIPVisionConfig, CLIPVisionModel, RobertaConfig, RobertaModel
+    import src.modeling.meta_arch.vqa_model as vm
+    from src.modeling.meta_arch.vqa_config import (VQAModelConfig, VisualEncoderConfig, TextEncoderConfig,
+                                                   FusionConfig, MOEConfig, KnowledgeConfig, AnswerHeadConfig)
+    d = dims
+
+    def vis_init(self):
+        self.backbone = CLIPVisionModel(CLIPVisionConfig(
+            hidden_size=d['D'], intermediate_size=d['vit_inter'], num_hidden_layers=d['vit_layers'],
+            num_attention_heads=d['vit_heads'], image_size=d['image'], patch_size=d['patch'],
+            hidden_act='quick_gelu', layer_norm_eps=1e-5))
+        self.backbone_dim, self.processor = d['D'], None
+
+    def txt_init(self):
+        self.encoder = RobertaModel(RobertaConfig(
+            vocab_size=d['vocab'], hidden_size=d['D'], num_hidden_layers=d['txt_layers'],
+            num_attention_heads=d['txt_heads'], intermediate_size=d['txt_inter'],
+            max_position_embeddings=d['max_pos'], type_vocab_size=1, pad_token_id=1, bos_token_id=0,
+            eos_token_id=2, layer_norm_eps=1e-5))
+        self.encoder_dim, self.tokenizer = d['D'], None
+
+    vm.VisualEncoder._init_backbone, vm.TextEncoder._init_encoder = vis_init, txt_init
+    cfg = VQAModelConfig(
+        visual_encoder=VisualEncoderConfig(output_dim=d['D']),
+        text_encoder=TextEncoderConfig(output_dim=d['D'], max_length=d['seq'], pooling_strategy=pooling),
+        fusion=FusionConfig(fusion_type=fusion_type, hidden_dim=d['D'], output_dim=d['D'],
+                            num_heads=d['fusion_heads'], num_layers=d['fusion_layers'], dropout=0.1),
+        moe=MOEConfig(use_moe=num_experts > 0, num_experts=max(num_experts, 1), top_k=2, hidden_dim=d['moe_hidden']),
+        knowledge=KnowledgeConfig(use_knowledge=False),
+        answer_head=AnswerHeadConfig(num_answers=d['num_answers'], hidden_dims=list(d['answer_hidden']), dropout=0.3))
+    return vm.VietnameseVQAModel(cfg).eval(), cfg
+
+
+def sample_grad(g, rich):
+    """Gradient sample stored in a fixture: the whole tensor when small, else head + strided sample
+    (``oracle.det_weights``-independent, so tests re-apply it to their own gradients)."""
+    f = g.detach().flatten()
+    head, nstr, full_below = (128, 256, 2048) if rich else (64, 64, 0)
+    if f.numel() <= max(full_below, head + nstr):
+        return f
+    stride = f.numel() // nstr
+    return torch.cat([f[:head], f[::stride][:nstr]])
+
+
+def run_model_case(tag, dims, fusion_type, num_experts, seed, full_grads):
+    model, cfg = build_reference_model(dims, fusion_type, num_experts)
+    shapes = dw.shapes_of(model.state_dict())
+    sd = dw.make_state_dict(shapes, seed)
+    model.load_state_dict(sd)
+    px, ids, mask, labels = dw.make_inputs(dims['batch'], dims['seq'], dims['image'],
+                                           vocab_hi=min(30000, dims['vocab']), num_answers=dims['num_answers'], seed=seed)
+    with torch.enable_grad():
+        out = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels, return_features=True)
+        out.loss.backward()
+    arrays = {'logits': out.logits.detach().numpy(), 'loss': out.loss.detach().numpy(),
+              'predictions': out.predictions.numpy(),
+              'visual_pooled': out.visual_features.detach().numpy(),
+              'text_pooled': out.text_features.detach().numpy(),
+              'fused': out.fused_features.detach().numpy()}
+    top2 = out.logits.detach().topk(2, dim=-1).values
+    arrays['margin'] = (top2[:, 0] - top2[:, 1]).numpy()
+    grad_names, none_names = [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            none_names.append(name)
+            continue
+        grad_names.append(name)
+        g = p.grad.detach()
+        arrays['gnorm/' + name] = np.float64(g.double().norm().item())
+        arrays['g/' + name] = sample_grad(g, full_grads).numpy().copy()
+    if num_experts > 0:
+        aux = model.moe_layer.aux_outputs
+        arrays['router_probs'] = aux['router_probs'].detach().numpy()
+        arrays['load_balance_loss'] = aux['load_balance_loss'].detach().numpy()
+    meta = dict(tag=tag, dims=dims, fusion_type=fusion_type, num_experts=num_experts, seed=seed,
+                full_grads=full_grads, shapes={k: list(v) for k, v in shapes.items()},
+                grad_names=grad_names, none_grad_names=none_names, weights_checksum=dw.checksum(sd),
+                torch=torch.__version__, transformers=__import__('transformers').__version__)
+    arrays['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f'{tag}.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'[gen_golden] {tag}: loss={float(out.loss):.6f} min-margin={float(arrays["margin"].min()):.4f} '
+          f'params={sum(p.numel() for p in model.parameters())} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
+
+
+def run_parts(seed=7):
+    """Component-level fixtures: routers (eval, injected-noise train, topk, soft), MOELayer combine with
+    ablation-style -1 indices, stand-alone CrossModalAttention with masks, text pooling variants."""
+    import src.modeling.meta_arch.vqa_model as vm
+    from src.modeling.moe.router import NoisyTopKRouter, TopKRouter, SoftRouter
+    from src.modeling.moe.moe_layer import MOELayer
+    arrays, meta = {}, {'seed': seed, 'cases': {}}
+
+    def load(mod, prefix):
+        shapes = {prefix + k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        sd = dw.make_state_dict(shapes, seed)
+        mod.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+        meta['cases'][prefix] = {k: list(v) for k, v in shapes.items()}
+        return sd
+
+    B, S, D, E, K = 3, 5, 32, 6, 2
+    x = dw.normal('parts.x', (B, S, D), seed)
+    # --- routers
+    r = NoisyTopKRouter(D, E, K).eval()
+    load(r, 'noisy.')
+    w, i, aux = r(x)
+    arrays.update({'noisy_eval/w': w.detach().numpy(), 'noisy_eval/i': i.numpy(),
+                   'noisy_eval/lb': aux['load_balance_loss'].detach().numpy(),
+                   'noisy_eval/probs': aux['router_probs'].detach().numpy()})
+    noise = dw.normal('parts.noise', (B, S, E), seed)
+    r.train()
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: noise.to(t.dtype)
+    try:
+        w, i, aux = r(x)
+    finally:
+        torch.randn_like = orig
+    arrays.update({'noisy_train/w': w.detach().numpy(), 'noisy_train/i': i.numpy(),
+                   'noisy_train/lb': aux['load_balance_loss'].detach().numpy()})
+    r = TopKRouter(D, E, 3).eval()
+    load(r, 'topk.')
+    w, i, aux = r(x)
+    arrays.update({'topk/w': w.detach().numpy(), 'topk/i': i.numpy(), 'topk/lb': aux['load_balance_loss'].detach().numpy()})
+    r = SoftRouter(D, E, temperature=0.7).eval()
+    load(r, 'soft.')
+    w, i, aux = r(x)
+    arrays.update({'soft/w': w.detach().numpy(), 'soft/i': i.numpy(), 'soft/entropy': aux['entropy'].detach().numpy()})
+    # --- MOELayer (feed-forward experts) with an ablation-style patched router: expert 1 disabled (-1)
+    layer = MOELayer(input_dim=D, hidden_dim=48, output_dim=D, num_experts=4, top_k=2, router_type='topk',
+                     expert_type='feedforward').eval()
+    load(layer, 'moeff.')
+    y = layer(x)
+    arrays['moeff/out'] = y.detach().numpy()
+    inner = layer.router.forward
+
+    def patched(inp, **kw):
+        w, i, aux = inner(inp, **kw)
+        dis = i == 1
+        w = w.masked_fill(dis, 0.0)
+        i = i.masked_fill(dis, -1)
+        w = w / w.sum(dim=-1, keepdim=True).clamp(min=1e-9)
+        return w, i, aux
+    layer.router.forward = patched
+    arrays['moeff/out_disabled1'] = layer(x).detach().numpy()
+    # --- CrossModalAttention with both masks
+    cma = vm.CrossModalAttention(D, 4, 0.1).eval()
+    load(cma, 'cma.')
+    kv = dw.normal('parts.kv', (B, 7, D), seed)
+    qm = torch.zeros(B, S, dtype=torch.bool)
+    qm[1, 3:] = True
+    km = torch.zeros(B, 7, dtype=torch.bool)
+    km[2, 5:] = True
+    xq = x.clone().requires_grad_(True)
+    kvq = kv.clone().requires_grad_(True)
+    y = cma(xq, kvq, qm, km)
+    (y * dw.normal('parts.gy', tuple(y.shape), seed)).sum().backward()
+    arrays.update({'cma/out': y.detach().numpy(), 'cma/dquery': xq.grad.numpy(), 'cma/dkv': kvq.grad.numpy()})
+    for n, p in cma.named_parameters():
+        arrays['cma/g/' + n] = p.grad.numpy()
+    # --- text pooling variants (vqa_model.py:179-204)
+    te = object.__new__(vm.TextEncoder)
+    am = torch.ones(B, S, dtype=torch.int64)
+    am[1, 3:] = 0
+    for strat in ('cls', 'mean', 'max'):
+        te.config = type('C', (), {'pooling_strategy': strat})()
+        arrays['pool/' + strat] = vm.TextEncoder._pool_features(te, x, am).numpy()
+    meta['dims'] = dict(B=B, S=S, D=D, E=E, K=K)
+    arrays['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, 'parts.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'[gen_golden] parts -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='all')
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    if args.only in ('all', 'parts'):
+        run_parts()
+    if args.only in ('all', 'tiny'):
+        run_model_case('tiny_concat', TINY, 'concat', 0, 11, True)
+        run_model_case('tiny_xattn', TINY, 'cross_attention', 0, 12, True)
+        run_model_case('tiny_mcan_moe4', TINY, 'mcan', 4, 13, True)
+        run_model_case('tiny_xattn_moe8', TINY, 'cross_attention', 8, 14, True)
+        run_model_case('tiny_bilinear', TINY, 'bilinear', 0, 15, True)
+    if args.only in ('all', 'full'):
+        run_model_case('full_cfg1_concat', FULL, 'concat', 0, 21, False)
+        run_model_case('full_cfg2_xattn', FULL, 'cross_attention', 0, 22, False)
+        run_model_case('full_cfg3_mcan_moe4', FULL, 'mcan', 4, 23, False)
+
+
+if __name__ == '__main__':
+    main()

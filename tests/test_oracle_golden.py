@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (oracle/vqa_oracle.py) against the golden vectors produced by the reference's
+own modules (oracle/gen_golden.py).  fp32 CPU vs fp32 CPU: tolerance 1e-5 relative."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import det_weights as dw
+from oracle import vqa_oracle as vo
+from oracle.gen_golden import sample_grad
+from tests.conftest import CfgView, load_golden
+
+TOL = 1e-5
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def _run_case(tag):
+    arrays, meta = load_golden(tag)
+    d = meta['dims']
+    shapes = {k: tuple(v) for k, v in meta['shapes'].items()}
+    sd = dw.make_state_dict(shapes, meta['seed'])
+    assert abs(dw.checksum(sd) - meta['weights_checksum']) <= 1e-6 * abs(meta['weights_checksum']), \
+        'deterministic weight generator drifted from the one that made the fixture'
+    px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=min(30000, d['vocab']),
+                                           num_answers=d['num_answers'], seed=meta['seed'])
+    cfg = CfgView(meta)
+    logits, loss, pred, grads = vo.forward_backward(sd, cfg, px, ids, mask, labels,
+                                                    vit_heads=d['vit_heads'], text_heads=d['txt_heads'])
+    return arrays, meta, logits, loss, pred, grads
+
+
+TINY = ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_xattn_moe8', 'tiny_bilinear']
+FULL = ['full_cfg1_concat', 'full_cfg2_xattn', 'full_cfg3_mcan_moe4']
+
+
+def _check(tag, rich):
+    arrays, meta, logits, loss, pred, grads = _run_case(tag)
+    assert rel_err(logits.numpy(), arrays['logits']) < TOL
+    assert abs(float(loss) - float(arrays['loss'])) < TOL * max(1.0, abs(float(arrays['loss'])))
+    assert np.array_equal(pred.numpy(), arrays['predictions'])          # argmax ids bit-exact
+    # parameters that get no gradient in the reference get none (or exact zeros) here
+    for name in meta['none_grad_names']:
+        assert name not in grads or float(grads[name].abs().max()) == 0.0, name
+    worst = 0.0
+    for name in meta['grad_names']:
+        assert name in grads, f'missing gradient for {name}'
+        g = grads[name]
+        gn = float(g.double().norm())
+        ref_n = float(arrays['gnorm/' + name])
+        assert abs(gn - ref_n) <= 2e-5 * ref_n + 1e-6, (name, gn, ref_n)   # 1e-6: fp32 noise floor of
+        #   gradients that are exactly zero in exact arithmetic (e.g. k_proj.bias: softmax shift invariance)
+        ref_s = arrays['g/' + name]
+        got_s = sample_grad(g, rich).numpy()
+        scale = max(np.abs(ref_s).max(), ref_n / np.sqrt(g.numel()), 1e-3)
+        e = float(np.abs(got_s - ref_s).max() / scale)
+        worst = max(worst, e)
+        assert e < 1e-4, (name, e)
+    return worst
+
+
+@pytest.mark.parametrize('tag', TINY)
+def test_oracle_matches_reference_tiny(tag):
+    _check(tag, True)
+
+
+@pytest.mark.parametrize('tag', FULL)
+def test_oracle_matches_reference_full(tag):
+    _check(tag, False)
+
+
+def test_parts_routers_combine_pooling():
+    arrays, meta = load_golden('parts')
+    seed = meta['seed']
+    dm = meta['dims']
+    B, S, D, E, K = dm['B'], dm['S'], dm['D'], dm['E'], dm['K']
+    x = dw.normal('parts.x', (B, S, D), seed)
+
+    def sd_for(prefix):
+        return dw.make_state_dict({k: tuple(v) for k, v in meta['cases'][prefix].items()}, seed)
+
+    sd = sd_for('noisy.')
+    w, i, aux = vo.noisy_topk_router(sd, 'noisy.', x, K)
+    assert np.array_equal(i.numpy(), arrays['noisy_eval/i'])
+    assert rel_err(w, arrays['noisy_eval/w']) < TOL
+    assert rel_err(aux['load_balance_loss'], arrays['noisy_eval/lb']) < TOL
+    assert rel_err(aux['router_probs'], arrays['noisy_eval/probs']) < TOL
+    noise = dw.normal('parts.noise', (B, S, E), seed)
+    w, i, aux = vo.noisy_topk_router(sd, 'noisy.', x, K, noise=noise)
+    assert np.array_equal(i.numpy(), arrays['noisy_train/i'])
+    assert rel_err(w, arrays['noisy_train/w']) < TOL
+    assert rel_err(aux['load_balance_loss'], arrays['noisy_train/lb']) < TOL
+
+    w, i, aux = vo.topk_router(sd_for('topk.'), 'topk.', x, 3)
+    assert np.array_equal(i.numpy(), arrays['topk/i']) and rel_err(w, arrays['topk/w']) < TOL
+    assert rel_err(aux['load_balance_loss'], arrays['topk/lb']) < TOL
+    w, i, aux = vo.soft_router(sd_for('soft.'), 'soft.', x, 0.7)
+    assert np.array_equal(i.numpy(), arrays['soft/i']) and rel_err(w, arrays['soft/w']) < TOL
+    assert rel_err(aux['entropy'], arrays['soft/entropy']) < TOL
+
+    # MOELayer with feed-forward experts; then with expert 1 disabled the way the ablation harness does it
+    sd = sd_for('moeff.')
+    kinds = ['feedforward'] * 4
+    ro = vo.topk_router(sd, 'moeff.router.', x, 2)
+    y, _ = vo.moe_layer(sd, 'moeff.', x, kinds, 2, router_out=ro)
+    assert rel_err(y, arrays['moeff/out']) < TOL
+    w, i, aux = ro
+    dis = i == 1
+    w2 = w.masked_fill(dis, 0.0)
+    i2 = i.masked_fill(dis, -1)
+    w2 = w2 / w2.sum(dim=-1, keepdim=True).clamp(min=1e-9)
+    y, _ = vo.moe_layer(sd, 'moeff.', x, kinds, 2, router_out=(w2, i2, aux))
+    assert rel_err(y, arrays['moeff/out_disabled1']) < TOL
+
+    # CrossModalAttention with query and key/value padding masks, forward + backward
+    sd = {k: v.requires_grad_(True) for k, v in sd_for('cma.').items()}
+    kv = dw.normal('parts.kv', (B, 7, D), seed).requires_grad_(True)
+    xq = x.clone().requires_grad_(True)
+    qm = torch.zeros(B, S, dtype=torch.bool)
+    qm[1, 3:] = True
+    km = torch.zeros(B, 7, dtype=torch.bool)
+    km[2, 5:] = True
+    y = vo.cross_modal_attention(sd, 'cma.', xq, kv, 4, qm, km)
+    (y * dw.normal('parts.gy', tuple(y.shape), seed)).sum().backward()
+    assert rel_err(y.detach(), arrays['cma/out']) < TOL
+    assert rel_err(xq.grad, arrays['cma/dquery']) < 5e-5
+    assert rel_err(kv.grad, arrays['cma/dkv']) < 5e-5
+    for k, v in sd.items():
+        assert rel_err(v.grad, arrays['cma/g/' + k[len('cma.'):]]) < 5e-5, k
+
+    am = torch.ones(B, S, dtype=torch.int64)
+    am[1, 3:] = 0
+    for strat in ('cls', 'mean', 'max'):
+        assert rel_err(vo.pool_text(x, am, strat), arrays['pool/' + strat]) < TOL
+
+
+def test_position_ids_pad_aware():
+    ids = torch.tensor([[0, 5, 1, 7, 2], [0, 9, 2, 1, 1]])
+    assert vo.roberta_position_ids(ids).tolist() == [[2, 3, 1, 4, 5], [2, 3, 4, 1, 1]]

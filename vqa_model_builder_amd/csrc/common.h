@@ -1,0 +1,79 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the VQA hot path.
+// Wavefront = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VQA_OK 0
+#define VQA_ERR_ARG 1001      // bad dims / alignment / unsupported combination
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+enum VqaAct { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3 };
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        default: return x;
+    }
+}
+// d act(x) / dx
+__device__ __forceinline__ float act_bwd(float x, int act) {
+    switch (act) {
+        case ACT_GELU_ERF: {
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case ACT_QUICK_GELU: {
+            const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+            return s * (1.0f + 1.702f * x * (1.0f - s));
+        }
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+// Counter-based RNG for dropout / router noise: one 32-bit hash per (seed, stream, index).
+// (Murmur3-style finaliser over a 64-bit key; statistically adequate for Bernoulli masks and
+//  Box-Muller noise, regenerated identically in forward and backward from the same key.)
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)stream << 40);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 16);
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
+    return (rng_u32(seed, stream, idx) >> 8) * (1.0f / 16777216.0f);   // [0,1)
+}
+// keep-scale for inverted dropout: 0 or 1/(1-p)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t stream, uint64_t idx, float p, float inv_keep) {
+    return rng_uniform(seed, stream, idx) >= p ? inv_keep : 0.f;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,336 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )      ("NT" convention)
+//
+// Operand layouts (per operand, chosen at run time -> template instance):
+//   k-contiguous ("KC"):  X(r,k) at x[r*ld + k]      -- activations [M,K], torch Linear weight [N,K]
+//   r-contiguous ("RC"):  X(r,k) at x[k*ld + r]      -- transposed views: dX = dY * W  (B = W as RC),
+//                                                       dW = dY^T * X   (A = dY as RC, B = X as RC)
+// KC tiles are staged [rows][64] with a 16-B-chunk XOR swizzle and read with ds_read_b128;
+// RC tiles are staged [64][rows] exactly as they lie in memory (coalesced along r) and the MFMA fragments
+// are produced by the CDNA4 transposing LDS read ds_read_b64_tr_b16, so no transposed copy of any tensor ever
+// exists in HBM.
+//
+// 256 threads = 4 waves arranged WM x WN; v_mfma_f32_16x16x32_bf16 with the operands swapped
+// (MFMA "A" = B-tile rows n, MFMA "B" = A-tile rows m) so that each lane ends up with 4 CONSECUTIVE n of one
+// row m: epilogue loads/stores are 8-16 B per lane and bias/residual/activation fuse without shuffles.
+//
+// Epilogue (all optional, fused):  + bias[n]  ->  * act'(act_grad_of[m,n])  ->  save pre-activation (bf16)
+//   -> act  ->  * dropout mask (counter RNG)  ->  + residual[m,n] (fp32)  ->  store fp32 and/or bf16.
+// split-K (gridDim.z > 1) accumulates fp32 partials with global_atomic_add_f32 into a pre-zeroed C.
+#include "common.h"
+#include "vqa_hip.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+    const bf16_t* a; const bf16_t* b;
+    int M, N, K, lda, ldb;
+    float* c_f32; int ldc_f32;
+    bf16_t* c_bf16; int ldc_bf16;
+    bf16_t* pre_bf16; int ld_pre;          // pre-activation save
+    const float* bias;                      // [N]
+    const float* residual; int ld_res;      // fp32 [M,N]
+    const bf16_t* act_grad_of; int ld_ag;   // multiply by act'(this) (backward through an activation)
+    int act;                                // activation applied in the epilogue (forward)
+    int act_bwd_kind;                       // activation whose derivative is applied (backward)
+    float alpha;
+    float drop_p; float drop_inv_keep; unsigned long long drop_seed; unsigned int drop_stream;
+    int k_per_split;                        // multiple of BK
+};
+
+// ---- LDS addressing -------------------------------------------------------------------------------------------
+// KC tile: [ROWS][64] bf16, 128-B rows, 8 chunks of 16 B; chunk ^= (row>>1)&7  -> ds_read_b128 conflict-free
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// RC tile: [64][ROWS] bf16 (ROWS*2-byte rows); 32-B (two-chunk) blocks are kept whole, block index XORed with a
+// key of the k-row so that the 8 k-rows one half-wave touches in a ds_read_b64_tr_b16 hit distinct banks.
+template <int ROWS>
+__device__ __forceinline__ int rc_off(int krow, int chunk) {
+    int key;
+    if (ROWS >= 128) key = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
+    else if (ROWS == 64) key = (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
+    else key = ((krow >> 3) & 1) << 1;
+    return krow * (ROWS * 2) + ((chunk ^ key) << 4);
+}
+
+template <int ROWS, bool KC>
+struct Stage {
+    static constexpr int CHUNKS = ROWS * BK / 8;
+    static constexpr int PT = (CHUNKS + NTHREADS - 1) / NTHREADS;   // chunks per thread
+    u32x4 v[PT];
+
+    // R = number of valid rows (M or N), Kend = end of this split's k range
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ g, int ld, int row0, int R, int k0, int Kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * NTHREADS;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (CHUNKS % NTHREADS == 0 || c < CHUNKS) {
+                if (KC) {
+                    const int row = c >> 3, kc = c & 7;
+                    const int gr = row0 + row, gk = k0 + kc * 8;
+                    if (gr < R && gk < Kend) z = *reinterpret_cast<const u32x4*>(g + (size_t)gr * ld + gk);
+                } else {
+                    constexpr int CPR = ROWS / 8;
+                    const int krow = c / CPR, rc = c % CPR;
+                    const int gk = k0 + krow, gr = row0 + rc * 8;
+                    if (gk < Kend && gr < R) z = *reinterpret_cast<const u32x4*>(g + (size_t)gk * ld + gr);
+                }
+            }
+            v[i] = z;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * NTHREADS;
+            if (CHUNKS % NTHREADS == 0 || c < CHUNKS) {
+                int off;
+                if (KC) off = kc_off(c >> 3, c & 7);
+                else { constexpr int CPR = ROWS / 8; off = rc_off<ROWS>(c / CPR, c % CPR); }
+                *reinterpret_cast<u32x4*>(lds + off) = v[i];
+            }
+        }
+    }
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// fragment of 16 rows (r0..r0+15) x 32 k (substep s) for lane: rows on lane&15, k = 8*(lane>>4)+j
+template <int ROWS, bool KC, bool USE_TR>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (KC) {
+        return *reinterpret_cast<const bf16x8*>(lds + kc_off(r0 + i, 4 * s + g));
+    } else if (USE_TR) {
+        // lane 4q+p of each 16-lane group addresses k-row q, columns 4p..4p+3 of the 4(k) x 16(r) block;
+        // it receives column i: element j = k-row j.
+        const int q = i >> 2, p = i & 3;
+        const int col = r0 + 4 * p;                       // multiple of 4 elements = 8 bytes
+        const int krow = 32 * s + 8 * g + q;
+        const int o0 = rc_off<ROWS>(krow, col >> 3) + ((col & 7) << 1);
+        const int o1 = rc_off<ROWS>(krow + 4, col >> 3) + ((col & 7) << 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        return u.v;
+    } else {
+        // portable fallback (no transposing read): 8 scalar 16-bit LDS reads
+        union { unsigned short h[8]; bf16x8 v; } u;
+        const int col = r0 + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int krow = 32 * s + 8 * g + j;
+            u.h[j] = *reinterpret_cast<const unsigned short*>(lds + rc_off<ROWS>(krow, col >> 3) + ((col & 7) << 1));
+        }
+        return u.v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool USE_TR>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: consecutive tiles of one M-row-panel share the A panel -> keep them on one XCD's L2
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    Stage<BM, A_KC> sa;
+    Stage<BN, B_KC> sb;
+    char* lds_a[2] = {smem, smem + A_BYTES + B_BYTES};
+    char* lds_b[2] = {smem + A_BYTES, smem + 2 * A_BYTES + B_BYTES};
+
+    if (nk > 0) {
+        sa.load(p.a, p.lda, m0, p.M, kbeg, kend, tid);
+        sb.load(p.b, p.ldb, n0, p.N, kbeg, kend, tid);
+        sa.store(lds_a[0], tid);
+        sb.store(lds_b[0], tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            sa.load(p.a, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+            sb.load(p.b, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+        }
+        const char* la = lds_a[cur];
+        const char* lb = lds_b[cur];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = load_frag<BM, A_KC, USE_TR>(la, wm * WTM + 16 * i, s, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = load_frag<BN, B_KC, USE_TR>(lb, wn * WTN + 16 * j, s, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            sa.store(lds_a[cur ^ 1], tid);
+            sb.store(lds_b[cur ^ 1], tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*WTM + 16*i + (lane&15), n = n0 + wn*WTN + 16*j + 4*(lane>>4)
+    const bool splitk = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + 16 * i + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + 16 * j + 4 * (lane >> 4);
+            if (n >= p.N) continue;                       // N % 4 == 0 is enforced on the host
+            f32x4 v = acc[i][j] * p.alpha;
+            if (splitk) {
+                float* dst = p.c_f32 + (size_t)m * p.ldc_f32 + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                continue;
+            }
+            if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
+            if (p.act_grad_of) {
+                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
+            }
+            if (p.pre_bf16) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+            }
+            if (p.act != ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+            }
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
+            }
+            if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
+            if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
+            if (p.c_bf16) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+            }
+        }
+    }
+}
+
+bool g_use_tr = true;
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    dim3 grid(tiles, 1, splits), block(NTHREADS);
+#define VQA_LAUNCH(AK, BKC, TR) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKC, TR>), grid, block, 0, st, p)
+    if (a_kc && b_kc) VQA_LAUNCH(true, true, true);
+    else if (a_kc && !b_kc) { if (g_use_tr) VQA_LAUNCH(true, false, true); else VQA_LAUNCH(true, false, false); }
+    else if (!a_kc && !b_kc) { if (g_use_tr) VQA_LAUNCH(false, false, true); else VQA_LAUNCH(false, false, false); }
+    else { if (g_use_tr) VQA_LAUNCH(false, true, true); else VQA_LAUNCH(false, true, false); }
+#undef VQA_LAUNCH
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
+
+extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, hipStream_t stream) {
+    if (!d || !d->a || !d->b || d->M <= 0 || d->N <= 0 || d->K <= 0) return VQA_ERR_ARG;
+    // 16-byte vector access requirements
+    if (d->lda % 8 || d->ldb % 8 || d->N % 4) return VQA_ERR_ARG;
+    if (d->a_kc ? (d->K % 8) : (d->M % 8)) return VQA_ERR_ARG;
+    if (d->b_kc ? (d->K % 8) : (d->N % 8)) return VQA_ERR_ARG;
+    if (((uintptr_t)d->a | (uintptr_t)d->b) & 15) return VQA_ERR_ARG;
+    if (d->c_f32 && (d->ldc_f32 % 4 || ((uintptr_t)d->c_f32 & 15))) return VQA_ERR_ARG;
+    if (d->c_bf16 && (d->ldc_bf16 % 4 || ((uintptr_t)d->c_bf16 & 7))) return VQA_ERR_ARG;
+    if (d->pre_bf16 && d->ld_pre % 4) return VQA_ERR_ARG;
+    if (d->residual && d->ld_res % 4) return VQA_ERR_ARG;
+    if (d->act_grad_of && d->ld_ag % 4) return VQA_ERR_ARG;
+    if (!d->c_f32 && !d->c_bf16 && !d->pre_bf16) return VQA_ERR_ARG;
+
+    GemmArgs p;
+    p.a = (const bf16_t*)d->a; p.b = (const bf16_t*)d->b;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
+    p.c_f32 = d->c_f32; p.ldc_f32 = d->ldc_f32;
+    p.c_bf16 = (bf16_t*)d->c_bf16; p.ldc_bf16 = d->ldc_bf16;
+    p.pre_bf16 = (bf16_t*)d->pre_bf16; p.ld_pre = d->ld_pre;
+    p.bias = d->bias; p.residual = d->residual; p.ld_res = d->ld_res;
+    p.act_grad_of = (const bf16_t*)d->act_grad_of; p.ld_ag = d->ld_ag;
+    p.act = d->act; p.act_bwd_kind = d->act_bwd;
+    p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+    p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
+
+    // tile choice: fill >= ~256 workgroups where the shape allows it
+    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N)
+    const long t128 = (long)ceil_div(d->M, 128) * ceil_div(d->N, 128);
+    if (d->tile_hint > 0) cfg = d->tile_hint - 1;
+    else if (d->M <= 32) cfg = 2;
+    else if (d->N <= 32) cfg = 3;
+    else if (t128 >= 200) cfg = 0;
+    else cfg = 1;
+    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : 128;
+    const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : 32;
+    const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
+
+    int splits = d->split_k;
+    const bool can_split = d->c_f32 && !d->c_bf16 && !d->pre_bf16 && !d->bias && !d->residual && !d->act_grad_of &&
+                           d->act == ACT_NONE && d->drop_p == 0.f;
+    if (splits <= 0) {
+        splits = 1;
+        if (can_split && d->allow_split_k) {
+            while (tiles * splits < 192 && d->K / (splits * 2) >= 4 * BK && splits < 16) splits *= 2;
+        }
+    }
+    if (splits > 1 && !can_split) return VQA_ERR_ARG;
+    int kps = ceil_div(ceil_div(d->K, splits), BK) * BK;
+    splits = ceil_div(d->K, kps);
+    p.k_per_split = kps;
+    if (splits > 1) {
+        hipError_t e = hipMemset2DAsync(d->c_f32, (size_t)d->ldc_f32 * 4, 0, (size_t)d->N * 4, d->M, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
+        case 1: return launch_cfg<64, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
+        case 2: return launch_cfg<32, 128, 1, 4>(p, d->a_kc, d->b_kc, splits, stream);
+        default: return launch_cfg<128, 32, 4, 1>(p, d->a_kc, d->b_kc, splits, stream);
+    }
+}
