@@ -1,0 +1,177 @@
+/* vqa_hip.h -- C ABI of libvqa_hip.so: the MI355X (gfx950) kernels behind the AutoViVQA hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: it sits behind a Python
+ * nn.Module API (reference src/modeling/meta_arch/vqa_model.py:480-756).  These entry points are what the
+ * reference-side binding for that path binds (INTEGRATION.md shows the ctypes stub); each one cites the
+ * reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a hipError_t value or VQA_ERR_ARG (1001) on bad arguments; nothing
+ *    throws, nothing synchronises, nothing allocates: the caller owns every buffer (outputs, saved-for-
+ *    backward tensors, workspaces) and passes the stream to launch on (vqa_stream_t = hipStream_t);
+ *  - pointers are device pointers; "bf16" buffers hold IEEE bfloat16 (2 bytes); all matrices row-major with an
+ *    explicit leading dimension in ELEMENTS; 16-byte aligned bases; feature dims multiples of 8;
+ *  - masks are uint8 (1 = ignore this key), token ids / labels are int64 like the torch tensors they alias.
+ */
+#ifndef VQA_HIP_H
+#define VQA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vqa_stream_t;
+
+#define VQA_ACT_NONE 0
+#define VQA_ACT_GELU_ERF 1    /* nn.GELU() / HF "gelu": vqa_model.py:267, modeling_roberta intermediate */
+#define VQA_ACT_QUICK_GELU 2  /* CLIP hidden_act: x*sigmoid(1.702x) */
+#define VQA_ACT_RELU 3        /* vqa_model.py:343,458 */
+
+int vqa_abi_version(void);
+
+/* ---- GEMM: C[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)) ------------------------------------------------
+ * Replaces every nn.Linear / packed in_proj on the path (torch F.linear; e.g. vqa_model.py:266-269,338,457,
+ * HF q/k/v/out_proj/fc1/fc2, expert_types.py:134-156) and their autograd (dX = dY W, dW = dY^T X).
+ * a_kc / b_kc: 1 = operand is k-contiguous (X(r,k) at x[r*ld+k]), 0 = r-contiguous (X(r,k) at x[k*ld+r]).
+ */
+typedef struct VqaGemmDesc {
+    const void* a; const void* b;          /* bf16 */
+    int M, N, K, lda, ldb, a_kc, b_kc;
+    float* c_f32; int ldc_f32;             /* optional fp32 output */
+    void* c_bf16; int ldc_bf16;            /* optional bf16 output */
+    void* pre_bf16; int ld_pre;            /* optional: pre-activation (after bias) saved as bf16 */
+    const float* bias;                     /* optional [N] */
+    const float* residual; int ld_res;     /* optional fp32 [M,N] added after activation/dropout */
+    const void* act_grad_of; int ld_ag;    /* optional bf16 [M,N]: multiply by act_bwd'(value) (backward) */
+    int act;                               /* VQA_ACT_* applied in the epilogue */
+    int act_bwd;                           /* VQA_ACT_* whose derivative act_grad_of selects */
+    float alpha;                           /* 0 means 1 */
+    float drop_p; uint64_t drop_seed; uint32_t drop_stream;   /* inverted dropout on the output, index m*N+n */
+    int split_k;                           /* 0 = auto (only if allow_split_k), 1 = off, >1 forced */
+    int allow_split_k;                     /* fp32 atomics into c_f32 (zeroed here); plain fp32 output only */
+    int tile_hint;                         /* 0 auto; 1:128x128 2:64x64 3:32x128 4:128x32 */
+} VqaGemmDesc;
+int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream);
+void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
+
+/* ---- elementwise / layout --------------------------------------------------------------------------------- */
+/* fp32 -> bf16 (weights shadow, activations); n elements */
+int vqa_cast_f32_bf16(const float* src, void* dst, size_t n, vqa_stream_t s);
+/* many tensors in one launch: jobs[i] = {src,dst,n,kind}; kind 0: f32->bf16, 1: f32->f32 copy.  jobs on device. */
+typedef struct VqaCastJob { const float* src; void* dst; uint64_t n; uint64_t kind; } VqaCastJob;
+int vqa_cast_multi(const VqaCastJob* jobs_dev, int njobs, uint64_t max_n, vqa_stream_t s);
+int vqa_cast_bf16_f32(const void* src, float* dst, size_t n, vqa_stream_t s);
+/* out[n] = sum_m x[m*ld+n]  (bias gradients); x bf16 or fp32 */
+int vqa_colsum_bf16(const void* x, int M, int N, int ld, float* out, vqa_stream_t s);
+int vqa_colsum_f32(const float* x, int M, int N, int ld, float* out, vqa_stream_t s);
+/* y = a + b (fp32), optional bf16 copy */
+int vqa_add_f32(const float* a, const float* b, float* y, void* y_bf16, size_t n, vqa_stream_t s);
+/* rows gather/scatter on fp32 [*,D]: dst[i,:] = src[idx[i],:] ; idx int32 */
+int vqa_gather_rows_f32(const float* src, const int32_t* idx, float* dst, void* dst_bf16, int n, int D, int ld_src, vqa_stream_t s);
+
+/* CLIP patch embedding im2col (HF CLIPVisionEmbeddings conv, stride == kernel, no bias): pixels fp32
+ * [B,3,H,W] -> bf16 [B*P, 3*ps*ps] with k = (c, kh, kw) as the conv weight is laid out. */
+int vqa_patchify_bf16(const float* pixels, void* out, int B, int C, int H, int W, int ps, vqa_stream_t s);
+/* u[b,0,:] = cls + pos[0]; u[b,1+p,:] = E[b*P+p,:] + pos[1+p]  (fp32 [B*T,D]) */
+int vqa_clip_assemble(const float* E, const float* cls, const float* pos, float* u, int B, int P, int D, vqa_stream_t s);
+/* backward of vqa_clip_assemble: dE bf16 [B*P,D] (for the patch GEMM dW), dcls[D], dpos[T,D] */
+int vqa_clip_assemble_bwd(const float* du, void* dE_bf16, float* dcls, float* dpos, int B, int P, int D, vqa_stream_t s);
+
+/* ---- LayerNorm (torch F.layer_norm, eps 1e-5; vqa_model.py:273-275,357 and every HF/expert LN) ------------ */
+/* y = LN(x (+ add)) * gamma + beta.  x fp32 [rows, cols]; optional add (fp32); outputs optional. */
+int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, const float* beta,
+                      float* y_f32, void* y_bf16, float* mean, float* rstd, int rows, int cols, float eps,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_stream, vqa_stream_t s);
+/* dx = dres (optional, fp32) + LN'(dy).  x = the LN input saved in forward.  dgamma/dbeta via partials:
+ * ws must hold vqa_layernorm_bwd_ws_floats(cols) floats.  dx_bf16 = optional bf16 copy of dx.
+ * drop_mode 1: dx_bf16 is additionally masked by the dropout (drop_*) that forward applied to the tensor
+ *              whose gradient it is (x = r + dropout(t): dx_bf16 is dt); dx_f32 stays unmasked (dr).
+ * drop_mode 2: dy is masked on load (forward was y = dropout(LN(x)) with the same drop_* at index row*cols+c). */
+size_t vqa_layernorm_bwd_ws_floats(int cols);
+int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* ws,
+                      int rows, int cols, float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode,
+                      vqa_stream_t s);
+
+/* ---- attention: softmax(Q K^T / sqrt(Dh) + key_padding) V per (batch, head) ------------------------------
+ * Replaces HF CLIP/RoBERTa self-attention and nn.MultiheadAttention's core (vqa_model.py:300,304).
+ * q/k/v/o are bf16 [B*S, ld] with head h at columns [h*Dh, (h+1)*Dh).  mask: uint8 [B, Skv], 1 = ignore. */
+typedef struct VqaAttnDesc {
+    const void* q; const void* k; const void* v; void* o;
+    int ldq, ldk, ldv, ldo;
+    int B, H, Sq, Skv, Dh;
+    const uint8_t* key_padding_mask;
+    float scale;                            /* 0 => Dh^-0.5 */
+    float drop_p; uint64_t drop_seed; uint32_t drop_stream;     /* dropout on the probabilities */
+    /* backward only */
+    const void* d_o; int ldd_o;
+    void* dq; void* dk; void* dv; int lddq, lddk, lddv;
+} VqaAttnDesc;
+int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s);
+int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s);
+
+/* ---- RoBERTa embeddings (HF RobertaEmbeddings: word + type0 + pad-aware positions, LN) --------------------- */
+/* pos_ids out: int32 [B,S] = cumsum(ids != pad) * (ids != pad) + pad.  u = sum of the three rows (fp32). */
+int vqa_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                          int32_t* pos_ids, float* u, int B, int S, int D, int pad_id, vqa_stream_t s);
+/* scatter-add du into dword/dpos (rows pad_id skipped: nn.Embedding padding_idx) and dtype0 = sum of all rows.
+ * dword [V,D] and dpos [Pmax,D] must be zero-filled by the caller; dtype0 [D]. */
+int vqa_roberta_embed_bwd(const float* du, const int64_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
+                          float* dtype0, int B, int S, int D, int pad_id, vqa_stream_t s);
+
+/* ---- loss (vqa_model.py:711-716: F.cross_entropy mean + argmax) ------------------------------------------- */
+/* per-row loss (fp32 [B]) and argmax (int64 [B]); loss_mean (fp32 [1]) = mean over rows. */
+int vqa_softmax_ce_argmax_fwd(const float* logits, int ld, const int64_t* labels, float* row_loss, float* loss_mean,
+                              int64_t* argmax, float* lse, int B, int C, vqa_stream_t s);
+/* dlogits = (softmax - onehot) * (*dloss) / B ; outputs fp32 and optional bf16 copy */
+int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss,
+                       float* dlogits, void* dlogits_bf16, int B, int C, vqa_stream_t s);
+
+/* ---- MoE router + dispatch (router.py:287-366, moe_layer.py:146-168); fp32 throughout ----------------------- */
+/* clean[t,e] = <x[t],gate[e]>;  noisy = clean (+ noise[t,e] * softplus(<x[t],w_noise[e]>) * noise_std when noise != NULL;
+ * noise_raw keeps <x,w_noise> for backward).  x fp32 [T,D], gate / w_noise fp32 [E,D] (nn.Linear, no bias). */
+int vqa_router_gate_fwd(const float* x, const float* gate, const float* w_noise, const float* noise, float noise_std,
+                        float* clean, float* noisy, float* noise_raw, int T, int E, int D, vqa_stream_t s);
+int vqa_router_gate_bwd(const float* x, const float* gate, const float* w_noise, const float* noise, float noise_std,
+                        const float* noise_raw, const float* dlogits, float* dgate, float* dw_noise, float* dx,
+                        int T, int E, int D, vqa_stream_t s);
+/* logits fp32 [T,E] -> softmax -> top-k (lowest index wins ties) -> renormalise by the k-sum.  probs_all optional. */
+int vqa_router_topk_fwd(const float* logits, float* weights, int64_t* indices, float* probs_all, int T, int E, int K,
+                        vqa_stream_t s);
+int vqa_router_topk_bwd(const float* logits, const int64_t* indices, const float* dweights, float* dlogits,
+                        int T, int E, int K, vqa_stream_t s);
+/* load_balance_loss = weight * E * sum_e (tokens_e/T) * mean_t probs[t,e]  (probs = softmax of the CLEAN logits) */
+int vqa_router_aux_loss(const float* probs, const int64_t* indices, int T, int E, int K, float weight, float* out, vqa_stream_t s);
+/* per expert e: combine weight w_all[e,t] = sum_k weights[t,k]*(indices[t,k]==e) (moe_layer.py:160-161), the
+ * order-preserving list of its tokens lists[e, 0:counts[e]] and counts[e].  Indices outside [0,E) (the ablation
+ * harness writes -1) route nowhere.  weights/indices may have any K <= 16. */
+int vqa_moe_expert_tokens(const float* weights, const int64_t* indices, int T, int K, int E, float* w_all, int32_t* lists,
+                          int32_t* counts, vqa_stream_t s);
+/* out[list[i],:] += w_tok[list[i]] * y[i,:]   (fp32; moe_layer.py:167-168 on the routed rows only) */
+int vqa_moe_scatter_add(const float* y, const int32_t* list, const float* w_tok, float* out, int n, int D, vqa_stream_t s);
+/* backward of the line above: dy[i,:] = w*dout[list[i],:] (fp32 and/or bf16), dw_tok[list[i]] = <dout[list[i]], y[i]> */
+int vqa_moe_combine_bwd(const float* dout, const float* y, const int32_t* list, const float* w_tok, float* dy, void* dy_bf16,
+                        float* dw_tok, int n, int D, vqa_stream_t s);
+/* dweights[t,k] = dw_all[indices[t,k], t] */
+int vqa_moe_route_weight_grad(const float* dw_all, const int64_t* indices, float* dweights, int T, int E, int K, vqa_stream_t s);
+/* counter-RNG helpers: N(0,1) noise for the noisy router; stand-alone inverted dropout (vqa_model.py:705) */
+int vqa_randn_f32(float* out, uint64_t n, uint64_t seed, uint32_t stream, vqa_stream_t s);
+int vqa_dropout_f32(const float* x, float* y, void* y_bf16, uint64_t n, float p, uint64_t seed, uint32_t stream, vqa_stream_t s);
+
+/* ---- fused AdamW (torch.optim.AdamW semantics; reference training_pipeline.py:234-287) --------------------- */
+typedef struct VqaAdamWDesc {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq; void* param_bf16 /* optional shadow */;
+    uint64_t n;
+    float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2;
+    const float* grad_scale;                /* optional device scalar multiplied into grad (clip coefficient) */
+} VqaAdamWDesc;
+int vqa_adamw_step(const VqaAdamWDesc* d, vqa_stream_t s);
+/* sum of squares of a fp32 buffer accumulated into out[0] (atomic; caller zeroes) */
+int vqa_sumsq_f32(const float* x, uint64_t n, float* out, vqa_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

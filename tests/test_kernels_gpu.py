@@ -1,0 +1,350 @@
+"""Per-kernel numerics on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 reference of the
+same op (torch ops here are the checker only).  Integer-valued bf16 data makes the GEMM layout checks EXACT."""
+
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from vqa_model_builder_amd.hip import kernels as K  # noqa: E402
+from vqa_model_builder_amd.hip import lib as hl  # noqa: E402
+
+DEV = 'cuda'
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def ints(shape, lo=-4, hi=5, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+def rnd(shape, seed=0, std=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.randn(shape, generator=g) * std)
+
+
+@pytest.fixture(autouse=True)
+def _sync():
+    yield
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM layouts
+SHAPES = [(128, 128, 64), (256, 384, 192), (1600, 768, 768), (50, 3000, 512), (32, 768, 3000), (8, 40, 64),
+          (200, 2304, 776), (96, 64, 24), (2048, 768, 3072)]
+
+
+@pytest.mark.parametrize('use_tr', [1, 0])
+@pytest.mark.parametrize('hint', [0, 1, 2, 3, 4])
+def test_gemm_layouts_exact(hint, use_tr):
+    hl.load().vqa_set_gemm_use_tr(use_tr)
+    try:
+        for (M, N, Kd) in SHAPES:
+            if use_tr == 0 and M * N * Kd > 4e8:
+                continue
+            a = ints((M, Kd), seed=M + Kd).to(DEV)
+            b = ints((N, Kd), seed=N + 7).to(DEV)
+            ref = a @ b.t()                                     # exact: |sum| < 2^24
+            # NT: both k-contiguous
+            out = torch.empty((M, N), dtype=F32, device=DEV)
+            K.gemm(a.to(BF), b.to(BF), M, N, Kd, Kd, Kd, True, True, out_f32=out, tile_hint=hint)
+            assert torch.equal(out, ref), ('NT', M, N, Kd, hint)
+            if N % 8 == 0:
+                # NN: B given as [K,N] (r-contiguous)
+                out.zero_()
+                K.gemm(a.to(BF), b.t().contiguous().to(BF), M, N, Kd, Kd, N, True, False, out_f32=out, tile_hint=hint)
+                assert torch.equal(out, ref), ('NN', M, N, Kd, hint)
+            if M % 8 == 0 and N % 8 == 0:
+                # TN: A given as [K,M], B as [K,N]
+                out.zero_()
+                K.gemm(a.t().contiguous().to(BF), b.t().contiguous().to(BF), M, N, Kd, M, N, False, False, out_f32=out,
+                       tile_hint=hint)
+                assert torch.equal(out, ref), ('TN', M, N, Kd, hint)
+                out.zero_()
+                K.gemm(a.t().contiguous().to(BF), b.to(BF), M, N, Kd, M, Kd, False, True, out_f32=out, tile_hint=hint)
+                assert torch.equal(out, ref), ('TK', M, N, Kd, hint)
+    finally:
+        hl.load().vqa_set_gemm_use_tr(1)
+
+
+def test_gemm_splitk_and_bf16_out():
+    M, N, Kd = 768, 768, 2048
+    a, b = ints((M, Kd), seed=1).to(DEV), ints((N, Kd), seed=2).to(DEV)
+    ref = a @ b.t()
+    out = torch.full((M, N), 7.0, dtype=F32, device=DEV)
+    K.gemm(a.t().contiguous().to(BF), b.t().contiguous().to(BF), M, N, Kd, M, N, False, False, out_f32=out, allow_split_k=True)
+    assert torch.equal(out, ref)
+    out.fill_(3.0)
+    K.gemm(a.to(BF), b.to(BF), M, N, Kd, Kd, Kd, out_f32=out, split_k=4, allow_split_k=True)
+    assert torch.equal(out, ref)
+    ob = torch.empty((M, N), dtype=BF, device=DEV)
+    K.gemm(a.to(BF), b.to(BF), M, N, Kd, Kd, Kd, out_bf16=ob)
+    assert torch.equal(ob, ref.to(BF))
+
+
+@pytest.mark.parametrize('act', [K.ACT_NONE, K.ACT_GELU, K.ACT_QUICK_GELU, K.ACT_RELU])
+def test_gemm_epilogue(act):
+    M, N, Kd = 200, 256, 320
+    x, w = rnd((M, Kd), 1).to(DEV).to(BF), rnd((N, Kd), 2, 0.05).to(DEV).to(BF)
+    bias, res = rnd((N,), 3).to(DEV), rnd((M, N), 4).to(DEV)
+    pre_ref = x.float() @ w.float().t() + bias
+    f = {K.ACT_NONE: lambda t: t, K.ACT_GELU: torch.nn.functional.gelu, K.ACT_QUICK_GELU: lambda t: t * torch.sigmoid(1.702 * t),
+         K.ACT_RELU: torch.relu}[act]
+    yf, yb, pre = K.linear_fwd(x, w, bias, M, N, Kd, want_f32=True, want_bf16=True, want_pre=True, act=act, residual=res)
+    assert torch.allclose(pre.float(), pre_ref, atol=2e-2, rtol=1e-2)
+    assert torch.allclose(yf, f(pre_ref) + res, atol=2e-3, rtol=1e-3)
+    assert torch.allclose(yb.float(), f(pre_ref) + res, atol=3e-2, rtol=1e-2)
+    # backward-through-activation epilogue: dx = (dy W) * act'(pre)
+    dy = rnd((M, N), 5).to(DEV).to(BF)
+    p = pre_ref.clone().requires_grad_(True)
+    f(p).backward(torch.ones_like(p))
+    agrad = rnd((M, Kd), 6).to(DEV).to(BF)          # stands for a saved pre-activation of width Kd
+    q = agrad.float().clone().requires_grad_(True)
+    f(q).backward(torch.ones_like(q))
+    dxf, _ = K.linear_dx(dy, w, M, N, Kd, want_f32=True, act_grad_of=agrad, act_bwd=act)
+    ref = (dy.float() @ w.float()) * q.grad
+    assert torch.allclose(dxf, ref, atol=3e-3, rtol=2e-3)
+
+
+def test_gemm_dropout_statistics_and_determinism():
+    M, N, Kd = 512, 512, 64
+    x, w = torch.ones((M, Kd), device=DEV, dtype=BF), torch.ones((N, Kd), device=DEV, dtype=BF) / Kd
+    d = K.Drop(0.3, 1234, 5)
+    y1, _, _ = K.linear_fwd(x, w, None, M, N, Kd, want_f32=True, drop=d)
+    y2, _, _ = K.linear_fwd(x, w, None, M, N, Kd, want_f32=True, drop=d)
+    assert torch.equal(y1, y2)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    assert torch.allclose(y1[y1 != 0], torch.full_like(y1[y1 != 0], 1 / 0.7), rtol=1e-2)
+    # the same mask is reproduced by the stand-alone dropout and by dx epilogue with the same key
+    z, _ = K.dropout_f32(torch.ones((M, N), device=DEV), d)
+    assert torch.equal(z != 0, y1 != 0)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize('cols', [64, 768, 2048, 4096, 40])
+def test_layernorm_fwd_bwd(cols):
+    rows = 333
+    x, add = rnd((rows, cols), 1).to(DEV), rnd((rows, cols), 2).to(DEV)
+    g, b = (1 + 0.1 * rnd((cols,), 3)).to(DEV), rnd((cols,), 4).to(DEV)
+    y, yb, mean, rstd = K.layernorm_fwd(x, g, b, rows, cols, add=add, want_bf16=True)
+    xs = (x + add).requires_grad_(True)
+    gg, bb = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xs, (cols,), gg, bb, 1e-5)
+    assert torch.allclose(y, ref, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(yb.float(), ref, atol=2e-2, rtol=1e-2)
+    dy, dres = rnd((rows, cols), 5).to(DEV), rnd((rows, cols), 6).to(DEV)
+    ref.backward(dy)
+    dx, dxb, dg, db = K.layernorm_bwd(dy, x + add, mean, rstd, g, rows, cols, dres=dres, want_bf16=True)
+    assert torch.allclose(dx, xs.grad + dres, atol=5e-5, rtol=1e-4)
+    assert torch.allclose(dxb.float(), xs.grad + dres, atol=5e-2, rtol=2e-2)
+    assert torch.allclose(dg, gg.grad, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(db, bb.grad, atol=2e-3, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _ref_attn(q, k, v, B, H, Sq, Skv, Dh, mask):
+    qh = q.view(B, Sq, H, Dh).transpose(1, 2)
+    kh = k.view(B, Skv, H, Dh).transpose(1, 2)
+    vh = v.view(B, Skv, H, Dh).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(Dh)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :].bool(), float('-inf'))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * Sq, H * Dh)
+
+
+@pytest.mark.parametrize('B,H,Sq,Skv,Dh,masked', [(3, 4, 8, 8, 16, True), (2, 12, 50, 50, 64, False), (2, 12, 64, 64, 64, True),
+                                                  (2, 8, 64, 50, 96, False), (3, 8, 4, 1, 256, False), (2, 8, 4, 4, 256, False),
+                                                  (2, 4, 17, 10, 16, True), (1, 2, 100, 128, 32, True)])
+def test_attention_fwd_bwd(B, H, Sq, Skv, Dh, masked):
+    D = H * Dh
+    # packed layouts with non-trivial leading dims: q in [.., 3D] at col 0, k/v in a [.., 2D] buffer
+    qbuf = rnd((B * Sq, 3 * D), 1).to(DEV).to(BF)
+    kvbuf = rnd((B * Skv, 2 * D), 2).to(DEV).to(BF)
+    q, k, v = qbuf[:, :D], kvbuf[:, :D], kvbuf[:, D:]
+    mask = None
+    if masked:
+        mask = torch.zeros((B, Skv), dtype=torch.uint8, device=DEV)
+        mask[0, Skv // 2:] = 1
+        mask[-1, -1] = 1
+    o = K.attention_fwd(q, k, v, 3 * D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, mask)
+    qf, kf, vf = [t.float().contiguous().requires_grad_(True) for t in (q, k, v)]
+    ref = _ref_attn(qf, kf, vf, B, H, Sq, Skv, Dh, mask)
+    assert torch.allclose(o.float(), ref, atol=2e-2, rtol=2e-2)
+    do = rnd((B * Sq, D), 3).to(DEV).to(BF)
+    ref.backward(do.float())
+    dq = torch.empty((B * Sq, D), dtype=BF, device=DEV)
+    dkv = torch.empty((B * Skv, 2 * D), dtype=BF, device=DEV)
+    K.attention_bwd(q, k, v, do, 3 * D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, dq, dkv[:, :D], dkv[:, D:], D, 2 * D, 2 * D, mask)
+    for got, want in ((dq, qf.grad), (dkv[:, :D], kf.grad), (dkv[:, D:], vf.grad)):
+        err = (got.float() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+        assert err < 2e-2, err
+
+
+def test_attention_dropout_consistency():
+    B, H, Sq, Skv, Dh = 2, 4, 16, 16, 32
+    D = H * Dh
+    q, k, v = [rnd((B * Sq, D), i).to(DEV).to(BF) for i in range(3)]
+    d = K.Drop(0.25, 99, 3)
+    o1 = K.attention_fwd(q, k, v, D, D, D, B, H, Sq, Skv, Dh, None, d)
+    o2 = K.attention_fwd(q, k, v, D, D, D, B, H, Sq, Skv, Dh, None, d)
+    assert torch.equal(o1, o2)
+    o0 = K.attention_fwd(q, k, v, D, D, D, B, H, Sq, Skv, Dh, None)
+    assert not torch.equal(o0, o1)
+    # with V = ones the output equals the kept probability mass / keep: mean over many rows ~ 1
+    ones = torch.ones_like(v)
+    om = K.attention_fwd(q, k, ones, D, D, D, B, H, Sq, Skv, Dh, None, d).float().mean().item()
+    assert abs(om - 1.0) < 0.08
+
+
+# ------------------------------------------------------------------------------------------------ front ends
+def test_patchify_and_clip_assemble():
+    B, Cc, H, W, ps, D = 3, 3, 64, 96, 16, 32
+    px = rnd((B, Cc, H, W), 1).to(DEV)
+    out = K.patchify(px, ps)
+    ref = torch.nn.functional.unfold(px, ps, stride=ps).transpose(1, 2).reshape(-1, Cc * ps * ps)
+    assert torch.equal(out, ref.to(BF))
+    P = (H // ps) * (W // ps)
+    E, cls, pos = rnd((B * P, D), 2).to(DEV), rnd((D,), 3).to(DEV), rnd((P + 1, D), 4).to(DEV)
+    u = K.clip_assemble(E, cls, pos, B, P, D)
+    ref = torch.cat([cls.expand(B, 1, D), E.view(B, P, D)], 1) + pos[None]
+    assert torch.allclose(u.view(B, P + 1, D), ref)
+    du = rnd((B * (P + 1), D), 5).to(DEV)
+    dcls, dpos = torch.empty((D,), device=DEV), torch.empty((P + 1, D), device=DEV)
+    dE = K.clip_assemble_bwd(du, B, P, D, dcls, dpos)
+    duv = du.view(B, P + 1, D)
+    assert torch.allclose(dpos, duv.sum(0), atol=1e-5)
+    assert torch.allclose(dcls, duv[:, 0].sum(0), atol=1e-5)
+    assert torch.equal(dE.view(B, P, D), duv[:, 1:].to(BF))
+
+
+def test_roberta_embeddings():
+    B, S, D, V, Pm = 4, 16, 32, 50, 20
+    ids = torch.randint(2, V, (B, S), generator=torch.Generator().manual_seed(0))
+    ids[1, 10:] = 1
+    ids[0, 3] = 1
+    ids = ids.to(DEV)
+    word, pos, typ = rnd((V, D), 1).to(DEV), rnd((Pm, D), 2).to(DEV), rnd((1, D), 3).to(DEV)
+    u, pos_ids = K.roberta_embed_fwd(ids, word, pos, typ, B, S, D)
+    m = (ids != 1).int()
+    ref_pos = torch.cumsum(m, 1) * m + 1
+    assert torch.equal(pos_ids.long(), ref_pos.long())
+    ref = word[ids] + pos[ref_pos.long()] + typ[0]
+    assert torch.allclose(u.view(B, S, D), ref, atol=1e-6)
+    du = rnd((B * S, D), 4).to(DEV)
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.empty((D,), device=DEV)
+    K.roberta_embed_bwd(du, ids, pos_ids, dword, dpos, dtyp, B, S, D)
+    w2, p2 = word.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    r = torch.nn.functional.embedding(ids, w2, padding_idx=1) + torch.nn.functional.embedding(ref_pos.long(), p2, padding_idx=1)
+    r.backward(du.view(B, S, D))
+    assert torch.allclose(dword, w2.grad, atol=1e-5) and torch.allclose(dpos, p2.grad, atol=1e-5)
+    assert torch.allclose(dtyp, du.sum(0), atol=1e-4)
+
+
+def test_cross_entropy_argmax():
+    B, Cn = 37, 3000
+    logits = rnd((B, Cn), 1, 2.0).to(DEV)
+    logits[3, 100] = logits[3, 2000] = 50.0          # tie: first index wins like torch.argmax
+    labels = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    loss, pred, lse = K.ce_argmax_fwd(logits, labels, B, Cn)
+    lg = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lg, labels)
+    assert torch.allclose(loss, ref, atol=1e-5)
+    assert torch.equal(pred, logits.argmax(-1)) and pred[3].item() == 100
+    (ref * 2.5).backward()
+    dl, dlb = K.ce_bwd(logits, labels, lse, torch.tensor(2.5, device=DEV), B, Cn, want_bf16=True)
+    assert torch.allclose(dl, lg.grad, atol=1e-7, rtol=1e-4)
+
+
+def test_router_and_dispatch():
+    T, E, Kk, D = 37, 6, 2, 64
+    lib = hl.load()
+    x, gate, wn = rnd((T, D), 1).to(DEV), rnd((E, D), 2, 0.2).to(DEV), rnd((E, D), 3, 0.2).to(DEV)
+    noise = rnd((T, E), 4).to(DEV)
+    clean, noisy, nraw = [torch.empty((T, E), device=DEV) for _ in range(3)]
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.vqa_router_gate_fwd(x.data_ptr(), gate.data_ptr(), wn.data_ptr(), noise.data_ptr(), 1.0, clean.data_ptr(),
+                                   noisy.data_ptr(), nraw.data_ptr(), T, E, D, st) == 0
+    xr, gr, wr = [t.clone().requires_grad_(True) for t in (x, gate, wn)]
+    ref_clean = xr @ gr.t()
+    ref_noisy = ref_clean + noise * torch.nn.functional.softplus(xr @ wr.t())
+    assert torch.allclose(clean, ref_clean, atol=1e-5) and torch.allclose(noisy, ref_noisy, atol=1e-5)
+    w, idx, probs = torch.empty((T, Kk), device=DEV), torch.empty((T, Kk), dtype=torch.int64, device=DEV), torch.empty((T, E), device=DEV)
+    assert lib.vqa_router_topk_fwd(noisy.data_ptr(), w.data_ptr(), idx.data_ptr(), probs.data_ptr(), T, E, Kk, st) == 0
+    rp = torch.softmax(ref_noisy, -1)
+    rw, ri = torch.topk(rp, Kk, -1)
+    rwn = rw / rw.sum(-1, keepdim=True)
+    assert torch.equal(idx, ri) and torch.allclose(w, rwn, atol=1e-6) and torch.allclose(probs, rp, atol=1e-6)
+    dw = rnd((T, Kk), 5).to(DEV)
+    rwn.backward(dw)
+    dlog = torch.empty((T, E), device=DEV)
+    assert lib.vqa_router_topk_bwd(noisy.data_ptr(), idx.data_ptr(), dw.data_ptr(), dlog.data_ptr(), T, E, Kk, st) == 0
+    dgate, dwn, dx = torch.empty_like(gate), torch.empty_like(wn), torch.empty_like(x)
+    assert lib.vqa_router_gate_bwd(x.data_ptr(), gate.data_ptr(), wn.data_ptr(), noise.data_ptr(), 1.0, nraw.data_ptr(),
+                                   dlog.data_ptr(), dgate.data_ptr(), dwn.data_ptr(), dx.data_ptr(), T, E, D, st) == 0
+    assert torch.allclose(dgate, gr.grad, atol=1e-5) and torch.allclose(dwn, wr.grad, atol=1e-5)
+    assert torch.allclose(dx, xr.grad, atol=1e-5)
+    # dispatch lists, incl. an ablation-style -1 index
+    idx2 = idx.clone()
+    idx2[5, 0] = -1
+    w_all = torch.empty((E, T), device=DEV)
+    lists = torch.full((E, T), -7, dtype=torch.int32, device=DEV)
+    counts = torch.empty((E,), dtype=torch.int32, device=DEV)
+    assert lib.vqa_moe_expert_tokens(w.data_ptr(), idx2.data_ptr(), T, Kk, E, w_all.data_ptr(), lists.data_ptr(), counts.data_ptr(), st) == 0
+    out = torch.zeros((T, D), device=DEV)
+    ref_out = torch.zeros((T, D), device=DEV)
+    for e in range(E):
+        sel = (idx2 == e)
+        toks = sel.any(-1).nonzero().flatten()
+        assert counts[e].item() == toks.numel()
+        assert torch.equal(lists[e, :toks.numel()].long(), toks)
+        we = (w * sel.float()).sum(-1)
+        assert torch.allclose(w_all[e], we)
+        y = rnd((max(toks.numel(), 1), D), 10 + e).to(DEV)[:toks.numel()]
+        if toks.numel():
+            assert lib.vqa_moe_scatter_add(y.data_ptr(), lists[e].data_ptr(), w_all[e].data_ptr(), out.data_ptr(), toks.numel(), D, st) == 0
+            ref_out[toks] += y * we[toks, None]
+    assert torch.allclose(out, ref_out, atol=1e-6)
+
+
+def test_adamw_matches_torch():
+    n = 10007
+    p0, g = rnd((n,), 1).to(DEV), rnd((n,), 2).to(DEV)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-2, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    mine, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=BF, device=DEV)
+    lib = hl.load()
+    for step in range(1, 4):
+        p.grad = g * step
+        opt.step()
+        d = hl.VqaAdamWDesc()
+        gs = (g * step).contiguous()
+        d.param, d.grad, d.exp_avg, d.exp_avg_sq, d.param_bf16, d.n = mine.data_ptr(), gs.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), n
+        d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = 1e-2, 0.9, 0.999, 1e-8, 0.01
+        d.bias_correction1, d.bias_correction2, d.grad_scale = 1 - 0.9 ** step, 1 - 0.999 ** step, None
+        assert lib.vqa_adamw_step(C.byref(d), torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.allclose(mine, p.data, atol=1e-6, rtol=1e-5)
+    assert torch.equal(shadow, mine.to(BF))
+    ss = torch.zeros(1, device=DEV)
+    assert lib.vqa_sumsq_f32(g.data_ptr(), n, ss.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.allclose(ss[0], (g * g).sum(), rtol=1e-4)
+
+
+def test_casts_and_colsum():
+    x = rnd((1000, 96), 1).to(DEV)
+    assert torch.equal(K.cast_bf16(x), x.to(BF))
+    assert torch.equal(K.cast_f32(x.to(BF)), x.to(BF).float())
+    xb = x.to(BF)
+    assert torch.allclose(K.colsum_bf16(xb, 1000, 96), xb.float().sum(0), atol=1e-3)
+    big = rnd((5000, 768), 2).to(DEV)
+    assert torch.allclose(K.colsum_f32(big, 5000, 768), big.sum(0), atol=2e-3)
+    # multi-tensor cast: one bf16 job, one fp32-copy job, odd sizes
+    a, b = rnd((333,), 3).to(DEV), rnd((1001,), 4).to(DEV)
+    da, db = torch.empty(333, dtype=BF, device=DEV), torch.empty(1001, device=DEV)
+    jobs = torch.tensor([[a.data_ptr(), da.data_ptr(), 333, 0], [b.data_ptr(), db.data_ptr(), 1001, 1]], dtype=torch.int64, device=DEV)
+    K.cast_multi(jobs, 2, 1001)
+    assert torch.equal(da, a.to(BF)) and torch.equal(db, b)

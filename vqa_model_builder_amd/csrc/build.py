@@ -1,0 +1,57 @@
+"""Builds libvqa_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m vqa_model_builder_amd.csrc.build [--force]
+
+One object per .hip file (cached by mtime), linked into vqa_model_builder_amd/csrc/libvqa_hip.so.
+No torch headers are involved: the library is a plain C ABI (include/vqa_hip.h).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, 'libvqa_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(REPO, 'include'), '-I' + HERE,
+         '-Wno-unused-result']
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+
+
+def _stale(obj, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')] + [os.path.join(REPO, 'include', 'vqa_hip.h')]
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, src[:-4] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(HERE, src)] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ['-c', os.path.join(HERE, src), '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print('[build]', ' '.join(cmd[-3:]), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,294 @@
+// HBM-bound byte movers of the path: casts (weight shadows), column sums (bias gradients), CLIP patchify /
+// token assembly.  All 16-byte vector accesses, grid-stride, <= 2048 blocks (cdna guide, guideline 11/13).
+#include "common.h"
+#include "vqa_hip.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(size_t work_items) {
+    size_t g = (work_items + TPB - 1) / TPB;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    const size_t n8 = n / 8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = (bf16_t)a[j]; o[4 + j] = (bf16_t)b[j]; }
+        reinterpret_cast<bf16x8*>(dst)[i] = o;
+    }
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)src[i];
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
+}
+
+// one block-row (blockIdx.y) per job; blockIdx.x strides inside the job
+__global__ void cast_multi_kernel(const VqaCastJob* __restrict__ jobs) {
+    const VqaCastJob job = jobs[blockIdx.y];
+    const size_t n = job.n, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* src = job.src;
+    const bool vec_ok = (((uintptr_t)src | (uintptr_t)job.dst) & 15) == 0;
+    if (job.kind == 0) {
+        bf16_t* dst = (bf16_t*)job.dst;
+        size_t n8 = vec_ok ? n / 8 : 0;
+        for (size_t i = t0; i < n8; i += stride) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
+            const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = (bf16_t)a[j]; o[4 + j] = (bf16_t)b[j]; }
+            reinterpret_cast<bf16x8*>(dst)[i] = o;
+        }
+        for (size_t i = n8 * 8 + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
+    } else {
+        float* dst = (float*)job.dst;
+        size_t n4 = vec_ok ? n / 4 : 0;
+        for (size_t i = t0; i < n4; i += stride) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+        for (size_t i = n4 * 4 + t0; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+// column sums: block = 64 columns x 4 row-groups... each thread owns one column, loops rows with stride 4*gridDim.y
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, int M, int N, int ld, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (col < N) {
+        for (int m = blockIdx.y * 4 + rg; m < M; m += 4 * gridDim.y) acc += (float)x[(size_t)m * ld + col];
+    }
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && col < N) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (gridDim.y == 1) out[col] = v; else atomicAdd(out + col, v);
+    }
+}
+
+template <typename T>
+int colsum_launch(const T* x, int M, int N, int ld, float* out, hipStream_t s) {
+    if (!x || !out || M <= 0 || N <= 0) return VQA_ERR_ARG;
+    const int gx = ceil_div(N, 64);
+    int gy = 1;
+    while (gx * gy < 512 && M / (gy * 2) >= 64) gy *= 2;
+    if (gy > 1) { hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, s); if (e != hipSuccess) return (int)e; }
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, s, x, M, N, ld, out);
+    return (int)hipGetLastError();
+}
+
+__global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                               bf16_t* __restrict__ yb, size_t n) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+        if (y) reinterpret_cast<f32x4*>(y)[i] = v;
+        if (yb) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j]; reinterpret_cast<bf16x4*>(yb)[i] = o; }
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ dst,
+                                   bf16_t* __restrict__ dstb, int n, int D, int ld_src) {
+    const int d4 = D / 4;
+    const size_t total = (size_t)n * d4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int i = (int)(t / d4), c = (int)(t % d4);
+        const f32x4 v = reinterpret_cast<const f32x4*>(src + (size_t)idx[i] * ld_src)[c];
+        if (dst) reinterpret_cast<f32x4*>(dst + (size_t)i * D)[c] = v;
+        if (dstb) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j]; reinterpret_cast<bf16x4*>(dstb + (size_t)i * D)[c] = o; }
+    }
+}
+
+// pixels [B,C,H,W] fp32 -> out [B*P, C*ps*ps] bf16, row (b, py, px), column (c, kh, kw).  One thread = 4 kw.
+__global__ void patchify_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int B, int C, int H, int W, int ps) {
+    const int gw = W / ps, gh = H / ps, P = gw * gh, Kc = C * ps * ps, q4 = ps / 4;
+    const size_t total = (size_t)B * P * C * ps * q4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        size_t r = t;
+        const int kw4 = (int)(r % q4); r /= q4;
+        const int kh = (int)(r % ps); r /= ps;
+        const int c = (int)(r % C); r /= C;
+        const int p = (int)(r % P); const int b = (int)(r / P);
+        const int py = p / gw, pxx = p % gw;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(px + (((size_t)b * C + c) * H + (py * ps + kh)) * W + pxx * ps + kw4 * 4);
+        bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x4*>(out + ((size_t)b * P + p) * Kc + (c * ps + kh) * ps + kw4 * 4) = o;
+    }
+}
+
+__global__ void clip_assemble_kernel(const float* __restrict__ E, const float* __restrict__ cls, const float* __restrict__ pos,
+                                     float* __restrict__ u, int B, int P, int D) {
+    const int T = P + 1, d4 = D / 4;
+    const size_t total = (size_t)B * T * d4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int c = (int)(t % d4); const size_t row = t / d4;
+        const int tok = (int)(row % T), b = (int)(row / T);
+        f32x4 v = tok == 0 ? reinterpret_cast<const f32x4*>(cls)[c]
+                           : reinterpret_cast<const f32x4*>(E + ((size_t)b * P + tok - 1) * D)[c];
+        v += reinterpret_cast<const f32x4*>(pos + (size_t)tok * D)[c];
+        reinterpret_cast<f32x4*>(u + row * D)[c] = v;
+    }
+}
+
+// dpos[tok,:] = sum_b du[b,tok,:]; dcls = dpos-like sum of tok 0; dE = bf16(du[b,1+p,:]).  grid = (T, ceil(D/256))
+__global__ void clip_assemble_bwd_kernel(const float* __restrict__ du, bf16_t* __restrict__ dE, float* __restrict__ dcls,
+                                         float* __restrict__ dpos, int B, int P, int D) {
+    const int T = P + 1, tok = blockIdx.x, d = blockIdx.y * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float v = du[((size_t)b * T + tok) * D + d];
+        acc += v;
+        if (tok > 0) dE[((size_t)b * P + tok - 1) * D + d] = (bf16_t)v;
+    }
+    dpos[(size_t)tok * D + d] = acc;
+    if (tok == 0) dcls[d] = acc;
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adamw_kernel(const VqaAdamWDesc d) {
+    const float gs = d.grad_scale ? *d.grad_scale : 1.f;
+    const float step_size = d.lr / d.bias_correction1;
+    const float inv_sqrt_bc2 = rsqrtf(d.bias_correction2);
+    const uint64_t n4 = d.n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    bf16_t* shadow = (bf16_t*)d.param_bf16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 p = reinterpret_cast<f32x4*>(d.param)[i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(d.grad)[i] * gs;
+        f32x4 m = reinterpret_cast<f32x4*>(d.exp_avg)[i];
+        f32x4 v = reinterpret_cast<f32x4*>(d.exp_avg_sq)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p[j] *= 1.f - d.lr * d.weight_decay;
+            m[j] = d.beta1 * m[j] + (1.f - d.beta1) * g[j];
+            v[j] = d.beta2 * v[j] + (1.f - d.beta2) * g[j] * g[j];
+            const float denom = sqrtf(v[j]) * inv_sqrt_bc2 + d.eps;
+            p[j] -= step_size * (m[j] / denom);
+        }
+        reinterpret_cast<f32x4*>(d.param)[i] = p;
+        reinterpret_cast<f32x4*>(d.exp_avg)[i] = m;
+        reinterpret_cast<f32x4*>(d.exp_avg_sq)[i] = v;
+        if (shadow) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)p[j]; reinterpret_cast<bf16x4*>(shadow)[i] = o; }
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
+        float p = d.param[i] * (1.f - d.lr * d.weight_decay);
+        const float g = d.grad[i] * gs;
+        const float m = d.beta1 * d.exp_avg[i] + (1.f - d.beta1) * g;
+        const float v = d.beta2 * d.exp_avg_sq[i] + (1.f - d.beta2) * g * g;
+        p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + d.eps));
+        d.param[i] = p; d.exp_avg[i] = m; d.exp_avg_sq[i] = v;
+        if (shadow) shadow[i] = (bf16_t)p;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqa_abi_version(void) { return 1; }
+
+int vqa_cast_f32_bf16(const float* src, void* dst, size_t n, vqa_stream_t s) {
+    if (!src || !dst) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(TPB), 0, (hipStream_t)s, src, (bf16_t*)dst, n);
+    return (int)hipGetLastError();
+}
+
+int vqa_cast_bf16_f32(const void* src, float* dst, size_t n, vqa_stream_t s) {
+    if (!src || !dst) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)s, (const bf16_t*)src, dst, n);
+    return (int)hipGetLastError();
+}
+
+int vqa_cast_multi(const VqaCastJob* jobs_dev, int njobs, uint64_t max_n, vqa_stream_t s) {
+    if (!jobs_dev || njobs <= 0) return VQA_ERR_ARG;
+    int gx = (int)((max_n / 8 + TPB - 1) / TPB);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(cast_multi_kernel, dim3(gx, njobs), dim3(TPB), 0, (hipStream_t)s, jobs_dev);
+    return (int)hipGetLastError();
+}
+
+int vqa_colsum_bf16(const void* x, int M, int N, int ld, float* out, vqa_stream_t s) {
+    return colsum_launch<bf16_t>((const bf16_t*)x, M, N, ld, out, (hipStream_t)s);
+}
+int vqa_colsum_f32(const float* x, int M, int N, int ld, float* out, vqa_stream_t s) {
+    return colsum_launch<float>(x, M, N, ld, out, (hipStream_t)s);
+}
+
+int vqa_add_f32(const float* a, const float* b, float* y, void* y_bf16, size_t n, vqa_stream_t s) {
+    if (!a || !b || (!y && !y_bf16) || n % 4) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)s, a, b, y, (bf16_t*)y_bf16, n);
+    return (int)hipGetLastError();
+}
+
+int vqa_gather_rows_f32(const float* src, const int32_t* idx, float* dst, void* dst_bf16, int n, int D, int ld_src, vqa_stream_t s) {
+    if (!src || !idx || (!dst && !dst_bf16) || D % 4 || ld_src % 4 || n < 0) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n * D / 4)), dim3(TPB), 0, (hipStream_t)s, src, idx, dst,
+                       (bf16_t*)dst_bf16, n, D, ld_src);
+    return (int)hipGetLastError();
+}
+
+int vqa_patchify_bf16(const float* pixels, void* out, int B, int C, int H, int W, int ps, vqa_stream_t s) {
+    if (!pixels || !out || B <= 0 || ps % 4 || H % ps || W % ps || W % 4) return VQA_ERR_ARG;
+    const size_t total = (size_t)B * C * H * W / 4;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)s, pixels, (bf16_t*)out, B, C, H, W, ps);
+    return (int)hipGetLastError();
+}
+
+int vqa_clip_assemble(const float* E, const float* cls, const float* pos, float* u, int B, int P, int D, vqa_stream_t s) {
+    if (!E || !cls || !pos || !u || D % 4) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid_for((size_t)B * (P + 1) * D / 4)), dim3(TPB), 0, (hipStream_t)s, E, cls, pos, u, B, P, D);
+    return (int)hipGetLastError();
+}
+
+int vqa_clip_assemble_bwd(const float* du, void* dE_bf16, float* dcls, float* dpos, int B, int P, int D, vqa_stream_t s) {
+    if (!du || !dE_bf16 || !dcls || !dpos) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(clip_assemble_bwd_kernel, dim3(P + 1, ceil_div(D, 256)), dim3(256), 0, (hipStream_t)s, du, (bf16_t*)dE_bf16, dcls, dpos, B, P, D);
+    return (int)hipGetLastError();
+}
+
+int vqa_sumsq_f32(const float* x, uint64_t n, float* out, vqa_stream_t s) {
+    if (!x || !out) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    if ((uintptr_t)x & 15) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)s, x, n, out);
+    return (int)hipGetLastError();
+}
+
+int vqa_adamw_step(const VqaAdamWDesc* d, vqa_stream_t s) {
+    if (!d || !d->param || !d->grad || !d->exp_avg || !d->exp_avg_sq) return VQA_ERR_ARG;
+    if (d->n == 0) return VQA_OK;
+    if (((uintptr_t)d->param | (uintptr_t)d->grad | (uintptr_t)d->exp_avg | (uintptr_t)d->exp_avg_sq) & 15) return VQA_ERR_ARG;
+    if (d->param_bf16 && ((uintptr_t)d->param_bf16 & 7)) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(d->n / 4 + 1)), dim3(TPB), 0, (hipStream_t)s, *d);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// RoBERTa embedding gather / scatter-add and the cross-entropy + argmax head.  HBM/latency-bound row kernels:
+// one wavefront per row, 16-byte accesses, shuffles for the row reductions.
+#include "common.h"
+#include "vqa_hip.h"
+
+namespace {
+
+// one block per sample: pad-aware position ids by a block-wide inclusive scan over S <= 1024 tokens,
+// then u[b,s,:] = word[ids] + pos[pos_id] + type0
+__global__ void roberta_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                         const float* __restrict__ type0, int32_t* __restrict__ pos_ids, float* __restrict__ u,
+                                         int S, int D, int pad_id) {
+    extern __shared__ int scan[];                 // [S]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int s = tid; s < S; s += blockDim.x) scan[s] = ids[(size_t)b * S + s] != pad_id ? 1 : 0;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int s = 0; s < S; ++s) { const int m = scan[s]; run += m; scan[s] = m ? run + pad_id : pad_id; } }
+    __syncthreads();
+    for (int s = tid; s < S; s += blockDim.x) pos_ids[(size_t)b * S + s] = scan[s];
+    const int d4 = D / 4;
+    for (int t = tid; t < S * d4; t += blockDim.x) {
+        const int s = t / d4, c = t % d4;
+        const int64_t id = ids[(size_t)b * S + s];
+        f32x4 v = reinterpret_cast<const f32x4*>(word + (size_t)id * D)[c];
+        v += reinterpret_cast<const f32x4*>(pos + (size_t)scan[s] * D)[c];
+        v += reinterpret_cast<const f32x4*>(type0)[c];
+        reinterpret_cast<f32x4*>(u + ((size_t)b * S + s) * D)[c] = v;
+    }
+}
+
+// scatter-add rows of du into the (pre-zeroed) dense table gradients; pad rows are skipped (padding_idx)
+__global__ void roberta_embed_bwd_kernel(const float* __restrict__ du, const int64_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+                                         float* __restrict__ dword, float* __restrict__ dpos, int rows, int D, int pad_id) {
+    const size_t total = (size_t)rows * D, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int r = (int)(t / D), d = (int)(t % D);
+        const float g = du[t];
+        const int64_t id = ids[r];
+        const int pid = pos_ids[r];
+        if (id != pad_id) atomicAdd(dword + (size_t)id * D + d, g);
+        if (pid != pad_id) atomicAdd(dpos + (size_t)pid * D + d, g);
+    }
+}
+
+// ---- cross entropy: one wave per row ------------------------------------------------------------------------
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
+                              int64_t* __restrict__ argmax, float* __restrict__ lse_out, int B, int C) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* x = logits + (size_t)row * ld;
+    float m = -INFINITY; int mi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) { const float v = x[c]; if (v > m) { m = v; mi = c; } }    // first max per lane
+    // wave arg-max with lowest-index tie-break (torch.argmax returns the first maximal index)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += __expf(x[c] - m);
+    sum = wave_sum(sum);
+    const float lse = m + __logf(sum);
+    if (lane == 0) {
+        if (lse_out) lse_out[row] = lse;
+        if (argmax) argmax[row] = mi;
+        if (row_loss) row_loss[row] = labels ? lse - x[labels[row]] : 0.f;
+    }
+}
+
+__global__ void ce_mean_kernel(const float* __restrict__ row_loss, float* __restrict__ loss_mean, int B) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 64) acc += row_loss[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss_mean[0] = acc / B;
+}
+
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels, const float* __restrict__ lse,
+                              const float* __restrict__ dloss, float* __restrict__ dlogits, bf16_t* __restrict__ dlb, int B, int C) {
+    const float scale = dloss[0] / B;
+    const size_t total = (size_t)B * C, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int r = (int)(t / C), c = (int)(t % C);
+        float g = __expf(logits[(size_t)r * ld + c] - lse[r]);
+        if (labels[r] == c) g -= 1.f;
+        g *= scale;
+        if (dlogits) dlogits[t] = g;
+        if (dlb) dlb[t] = (bf16_t)g;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqa_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, int32_t* pos_ids, float* u,
+                          int B, int S, int D, int pad_id, vqa_stream_t s) {
+    if (!ids || !word || !pos || !type0 || !pos_ids || !u || B <= 0 || S <= 0 || S > 4096 || D % 4) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(roberta_embed_fwd_kernel, dim3(B), dim3(256), (size_t)S * 4, (hipStream_t)s, ids, word, pos, type0, pos_ids, u, S, D, pad_id);
+    return (int)hipGetLastError();
+}
+
+int vqa_roberta_embed_bwd(const float* du, const int64_t* ids, const int32_t* pos_ids, float* dword, float* dpos, float* dtype0,
+                          int B, int S, int D, int pad_id, vqa_stream_t s) {
+    if (!du || !ids || !pos_ids || !dword || !dpos || !dtype0) return VQA_ERR_ARG;
+    const size_t total = (size_t)B * S * D;
+    size_t g = (total + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(roberta_embed_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, du, ids, pos_ids, dword, dpos, B * S, D, pad_id);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return vqa_colsum_f32(du, B * S, D, D, dtype0, s);
+}
+
+int vqa_softmax_ce_argmax_fwd(const float* logits, int ld, const int64_t* labels, float* row_loss, float* loss_mean, int64_t* argmax,
+                              float* lse, int B, int C, vqa_stream_t s) {
+    if (!logits || B <= 0 || C <= 0 || (loss_mean && !row_loss)) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, labels, row_loss, argmax, lse, B, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (loss_mean && labels) {
+        hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, row_loss, loss_mean, B);
+        e = hipGetLastError();
+    }
+    return (int)e;
+}
+
+int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss, float* dlogits,
+                       void* dlogits_bf16, int B, int C, vqa_stream_t s) {
+    if (!logits || !labels || !lse || !dloss || (!dlogits && !dlogits_bf16)) return VQA_ERR_ARG;
+    size_t g = ((size_t)B * C + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, logits, ld, labels, lse, dloss, dlogits, (bf16_t*)dlogits_bf16, B, C);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -162,14 +162,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 
     Stage<BM, A_KC> sa;
     Stage<BN, B_KC> sb;
-    char* lds_a[2] = {smem, smem + A_BYTES + B_BYTES};
-    char* lds_b[2] = {smem + A_BYTES, smem + 2 * A_BYTES + B_BYTES};
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;           // buffer i: A tile at i*BUF_BYTES, B tile right behind it
 
     if (nk > 0) {
         sa.load(p.a, p.lda, m0, p.M, kbeg, kend, tid);
         sb.load(p.b, p.ldb, n0, p.N, kbeg, kend, tid);
-        sa.store(lds_a[0], tid);
-        sb.store(lds_b[0], tid);
+        sa.store(smem, tid);
+        sb.store(smem + A_BYTES, tid);
     }
     __syncthreads();
 
@@ -180,8 +179,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
             sa.load(p.a, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
             sb.load(p.b, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
         }
-        const char* la = lds_a[cur];
-        const char* lb = lds_b[cur];
+        const char* la = smem + cur * BUF_BYTES;
+        const char* lb = la + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 fa[TM], fb[TN];
@@ -196,8 +195,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            sa.store(lds_a[cur ^ 1], tid);
-            sb.store(lds_b[cur ^ 1], tid);
+            sa.store(smem + (cur ^ 1) * BUF_BYTES, tid);
+            sb.store(smem + (cur ^ 1) * BUF_BYTES + A_BYTES, tid);
         }
         __syncthreads();
     }
@@ -271,7 +270,8 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 
-extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, hipStream_t stream) {
+extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (!d || !d->a || !d->b || d->M <= 0 || d->N <= 0 || d->K <= 0) return VQA_ERR_ARG;
     // 16-byte vector access requirements
     if (d->lda % 8 || d->ldb % 8 || d->N % 4) return VQA_ERR_ARG;

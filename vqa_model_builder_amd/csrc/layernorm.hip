@@ -1,0 +1,217 @@
+// LayerNorm forward / backward for gfx950.  HBM-bound: one wavefront per row, 16-byte loads, the whole row lives
+// in registers between the statistics pass and the normalise pass (one read of x, one write of y), row reductions
+// by 64-lane shuffles (no LDS, no barriers in forward).  fp32 statistics and arithmetic, like torch under autocast.
+//
+// algorithmic bytes / row:  fwd  4*cols (x) [+4*cols add] + 4*cols (y fp32) and/or 2*cols (y bf16)
+//                           bwd  8*cols (dy, x) [+4*cols dres] + 4*cols and/or 2*cols (dx)
+#include "common.h"
+#include "vqa_hip.h"
+
+namespace {
+
+constexpr int WAVES = 4;                 // rows per block pass
+constexpr int MAXV = 16;                 // float4 per lane -> cols <= 64*4*16 = 4096
+
+template <int NV>
+__global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, bf16_t* __restrict__ yb, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    int rows, int cols, float eps, float drop_p, float inv_keep, uint64_t seed, uint32_t stream) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = cols / 4;
+    for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < c4) {
+                v[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[c];
+                if (add) v[i] += reinterpret_cast<const f32x4*>(add + (size_t)row * cols)[c];
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+        const float mean = wave_sum(s) / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < c4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+        if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < c4) {
+                const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c];
+                const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c];
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+                    if (drop_p > 0.f) o[j] *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
+                }
+                if (y) reinterpret_cast<f32x4*>(y + (size_t)row * cols)[c] = o;
+                if (yb) { bf16x4 ob; for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j]; reinterpret_cast<bf16x4*>(yb + (size_t)row * cols)[c] = ob; }
+            }
+        }
+    }
+}
+
+// backward: each wave walks rows; per-lane partial dgamma/dbeta stay in registers across the whole row loop, are
+// combined across the block's waves through LDS once, and written as one partial row per block:
+// ws[blockIdx.x][0:cols] = dgamma partial, ws[gridDim.x + blockIdx.x][..] = dbeta partial.
+template <int NV>
+__global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx, bf16_t* __restrict__ dxb,
+    float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [WAVES][2][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = cols / 4;
+    f32x4 dg[NV], db[NV], g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; g[i] = dg[i];
+        const int c = lane + 64 * i;
+        if (c < c4) g[i] = reinterpret_cast<const f32x4*>(gamma)[c];
+    }
+    for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        f32x4 xh[NV], gy[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; gy[i] = xh[i];
+            if (c < c4) {
+                f32x4 d = reinterpret_cast<const f32x4*>(dy + (size_t)row * cols)[c];
+                if (drop_mode == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
+                }
+                const f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xv[j] - mean) * rstd;
+                    gy[i][j] = d[j] * g[i][j];
+                    s1 += gy[i][j];
+                    s2 += gy[i][j] * xh[i][j];
+                    dg[i][j] += d[j] * xh[i][j];
+                    db[i][j] += d[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / cols;
+        s2 = wave_sum(s2) / cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < c4) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[i][j] - s1 - xh[i][j] * s2);
+                if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * cols)[c];
+                if (dx) reinterpret_cast<f32x4*>(dx + (size_t)row * cols)[c] = o;
+                if (dxb) {
+                    bf16x4 ob;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = o[j];
+                        if (drop_mode == 1) t *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
+                        ob[j] = (bf16_t)t;
+                    }
+                    reinterpret_cast<bf16x4*>(dxb + (size_t)row * cols)[c] = ob;
+                }
+            }
+        }
+    }
+    if (!ws) return;
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < c4) { l4[(wave * 2 + 0) * c4 + c] = dg[i]; l4[(wave * 2 + 1) * c4 + c] = db[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < c4; c += WAVES * 64) {
+        f32x4 a = l4[c], b = l4[c4 + c];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) { a += l4[(w * 2 + 0) * c4 + c]; b += l4[(w * 2 + 1) * c4 + c]; }
+        reinterpret_cast<f32x4*>(ws + (size_t)blockIdx.x * cols)[c] = a;
+        reinterpret_cast<f32x4*>(ws + (size_t)(gridDim.x + blockIdx.x) * cols)[c] = b;
+    }
+}
+
+// final reduce of the per-block partials: out[c] = sum_b ws[b][c]
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int cols, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblocks; ++k) { a += ws[(size_t)k * cols + c]; b += ws[(size_t)(nblocks + k) * cols + c]; }
+    if (dgamma) dgamma[c] = a;
+    if (dbeta) dbeta[c] = b;
+}
+
+constexpr int BWD_BLOCKS = 256;
+
+inline int nv_for(int cols) { return ceil_div(cols / 4, 64); }
+
+}  // namespace
+
+extern "C" {
+
+int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, const float* beta, float* y_f32, void* y_bf16,
+                      float* mean, float* rstd, int rows, int cols, float eps, float drop_p, uint64_t drop_seed,
+                      uint32_t drop_stream, vqa_stream_t s) {
+    if (!x || !gamma || !beta || (!y_f32 && !y_bf16) || rows < 0 || cols <= 0 || cols % 4 || cols > 4096) return VQA_ERR_ARG;
+    if (rows == 0) return VQA_OK;
+    const int grid = min(ceil_div(rows, WAVES), 2048);
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const int nv = nv_for(cols);
+#define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)s, x, add, gamma, beta, \
+                                      y_f32, (bf16_t*)y_bf16, mean, rstd, rows, cols, eps, drop_p, inv_keep, drop_seed, drop_stream)
+    if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4);
+    else if (nv <= 8) LN_FWD(8); else LN_FWD(16);
+#undef LN_FWD
+    return (int)hipGetLastError();
+}
+
+size_t vqa_layernorm_bwd_ws_floats(int cols) { return (size_t)2 * BWD_BLOCKS * cols; }
+
+int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                      float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int cols, float drop_p,
+                      uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s) {
+    if (drop_p <= 0.f) drop_mode = 0;
+    if (!dy || !x || !mean || !rstd || !gamma || rows <= 0 || cols <= 0 || cols % 4 || cols > 4096) return VQA_ERR_ARG;
+    if ((dgamma || dbeta) && !ws) return VQA_ERR_ARG;
+    const int grid = min(ceil_div(rows, WAVES), BWD_BLOCKS);
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float* wsp = (dgamma || dbeta) ? ws : nullptr;
+    const size_t lds_bytes = wsp ? (size_t)WAVES * 2 * cols * 4 : 0;
+    const int nv = nv_for(cols);
+#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(WAVES * 64), lds_bytes, (hipStream_t)s, dy, x, mean, rstd, \
+                                      gamma, dres, dx_f32, (bf16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode)
+    if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
+    else if (nv <= 8) LN_BWD(8); else {
+        // 16 float4/lane: 128 KiB of LDS for the cross-wave combine exceeds the default dynamic limit
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_set = true; }
+        LN_BWD(16);
+    }
+#undef LN_BWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (wsp) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)s, ws, grid, cols, dgamma, dbeta);
+        e = hipGetLastError();
+    }
+    return (int)e;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""Block runners: hand-scheduled forward AND backward of the three heavy structures of the path -- the CLIP ViT layer
+stack, the RoBERTa/PhoBERT layer stack and the CrossModalAttention fusion layer -- as straight sequences of kernel
+launches with every fusion the kernels' epilogues offer (bias, activation + saved pre-activation, residual add,
+dropout masks, activation derivative in dX, bf16 operand copies written by the producer).
+
+Conventions: the residual stream is fp32 (as under torch autocast, where LayerNorm/adds run in fp32); every GEMM
+operand is bf16; weight gradients are fp32.  Each runner's ``forward`` returns (output, saved) and ``backward`` takes
+(saved, grad_output) and returns a dict {param_key: fp32 grad}.  Host code is Python on PyTorch-ROCm (north star);
+torch supplies memory and the stream only.
+"""
+
+import torch
+
+from . import kernels as K
+from .kernels import Drop, NO_DROP
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def new_seed() -> int:
+    """Per-forward dropout seed from torch's CPU generator (honours torch.manual_seed; no device sync)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+def _mask_u8(mask_bool):
+    if mask_bool is None:
+        return None
+    return mask_bool.to(torch.uint8).contiguous()
+
+
+# ==================================================================================================================
+# CLIP ViT vision tower (pre-LN, quick-GELU)     reference: vqa_model.py:103-131 -> HF CLIPVisionModel
+# ==================================================================================================================
+
+class ClipRunner:
+    """W: object with .p(key)->fp32 parameter tensor and .s(key)->bf16/fp32 shadow view (see modeling.backbones)."""
+
+    def __init__(self, W, num_layers, D, heads, inter, patch, eps=1e-5):
+        self.W, self.L, self.D, self.H, self.I, self.ps, self.eps = W, num_layers, D, heads, inter, patch, eps
+
+    def forward(self, px):
+        W, D, H, I = self.W, self.D, self.H, self.I
+        B, C, Hh, Ww = px.shape
+        P = (Hh // self.ps) * (Ww // self.ps)
+        T, M, Kp = P + 1, B * (P + 1), C * self.ps * self.ps
+        xp = K.patchify(px.contiguous(), self.ps)
+        E, _, _ = K.linear_fwd(xp, W.s('patch_w'), None, B * P, D, Kp, want_f32=True)
+        u = K.clip_assemble(E, W.p('cls'), W.p('pos'), B, P, D)
+        x, _, mean0, rstd0 = K.layernorm_fwd(u, W.p('pre_ln.w'), W.p('pre_ln.b'), M, D, eps=self.eps)
+        saved = dict(B=B, P=P, xp=xp, u=u, mean0=mean0, rstd0=rstd0, layers=[])
+        for l in range(self.L):
+            k = f'l{l}.'
+            _, h1, m1, r1 = K.layernorm_fwd(x, W.p(k + 'ln1.w'), W.p(k + 'ln1.b'), M, D, want_f32=False, want_bf16=True, eps=self.eps)
+            _, qkv, _ = K.linear_fwd(h1, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), M, 3 * D, D, want_bf16=True)
+            ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, T, T, D // H)
+            x1, _, _ = K.linear_fwd(ctx, W.s(k + 'out_w'), W.p(k + 'out_b'), M, D, D, want_f32=True, residual=x)
+            _, h2, m2, r2 = K.layernorm_fwd(x1, W.p(k + 'ln2.w'), W.p(k + 'ln2.b'), M, D, want_f32=False, want_bf16=True, eps=self.eps)
+            _, g, a = K.linear_fwd(h2, W.s(k + 'fc1_w'), W.p(k + 'fc1_b'), M, I, D, want_bf16=True, want_pre=True, act=K.ACT_QUICK_GELU)
+            x2, _, _ = K.linear_fwd(g, W.s(k + 'fc2_w'), W.p(k + 'fc2_b'), M, D, I, want_f32=True, residual=x1)
+            saved['layers'].append((x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g))
+            x = x2
+        return x.view(B, T, D), saved
+
+    def backward(self, saved, dout):
+        W, D, H, I = self.W, self.D, self.H, self.I
+        B, P = saved['B'], saved['P']
+        T, M = P + 1, B * (P + 1)
+        G = {}
+        dx = dout.reshape(M, D).contiguous().float()
+        dxb = K.cast_bf16(dx)
+        for l in reversed(range(self.L)):
+            k = f'l{l}.'
+            x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g = saved['layers'][l]
+            _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU)
+            G[k + 'fc2_w'] = K.linear_dw(dxb, g, M, D, I)
+            G[k + 'fc2_b'] = K.colsum_bf16(dxb, M, D)
+            dh2, _ = K.linear_dx(da, W.s(k + 'fc1_w'), M, I, D, want_f32=True)
+            G[k + 'fc1_w'] = K.linear_dw(da, h2, M, I, D)
+            G[k + 'fc1_b'] = K.colsum_bf16(da, M, I)
+            dx1, dx1b, G[k + 'ln2.w'], G[k + 'ln2.b'] = K.layernorm_bwd(dh2, x1, m2, r2, W.p(k + 'ln2.w'), M, D, dres=dx, want_bf16=True)
+            _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
+            G[k + 'out_w'] = K.linear_dw(dx1b, ctx, M, D, D)
+            G[k + 'out_b'] = K.colsum_bf16(dx1b, M, D)
+            dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dx.device)
+            K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, T, T, D // H,
+                            dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D)
+            dh1, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True)
+            G[k + 'qkv_w'] = K.linear_dw(dqkv, h1, M, 3 * D, D)
+            G[k + 'qkv_b'] = K.colsum_bf16(dqkv, M, 3 * D)
+            dx, dxb, G[k + 'ln1.w'], G[k + 'ln1.b'] = K.layernorm_bwd(dh1, x, m1, r1, W.p(k + 'ln1.w'), M, D, dres=dx1, want_bf16=True)
+        du, _, G['pre_ln.w'], G['pre_ln.b'] = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('pre_ln.w'), M, D)
+        G['cls'] = torch.empty((D,), dtype=F32, device=dx.device)
+        G['pos'] = torch.empty((T, D), dtype=F32, device=dx.device)
+        dE = K.clip_assemble_bwd(du, B, P, D, G['cls'], G['pos'])
+        Kp = saved['xp'].shape[1]
+        G['patch_w'] = K.linear_dw(dE, saved['xp'], B * P, D, Kp)
+        return G
+
+
+# ==================================================================================================================
+# RoBERTa / PhoBERT encoder (post-LN, erf-GELU, pad-aware positions)   reference: vqa_model.py:206-234 -> HF RobertaModel
+# ==================================================================================================================
+
+class RobertaRunner:
+    def __init__(self, W, num_layers, D, heads, inter, pad_id=1, hidden_drop=0.1, attn_drop=0.1, eps=1e-5):
+        self.W, self.L, self.D, self.H, self.I = W, num_layers, D, heads, inter
+        self.pad, self.pd, self.pa, self.eps = pad_id, hidden_drop, attn_drop, eps
+
+    def forward(self, ids, attention_mask, training):
+        W, D, H, I = self.W, self.D, self.H, self.I
+        B, S = ids.shape
+        M = B * S
+        seed = new_seed() if training else 0
+        pd, pa = (self.pd, self.pa) if training else (0.0, 0.0)
+        ids = ids.contiguous()
+        kpm = _mask_u8(attention_mask == 0) if attention_mask is not None else None
+        u, pos_ids = K.roberta_embed_fwd(ids, W.p('word'), W.p('pos'), W.p('type'), B, S, D, self.pad)
+        x, xb, mean0, rstd0 = K.layernorm_fwd(u, W.p('emb_ln.w'), W.p('emb_ln.b'), M, D, want_bf16=True, eps=self.eps,
+                                              drop=Drop(pd, seed, 1))
+        saved = dict(B=B, S=S, ids=ids, pos_ids=pos_ids, u=u, mean0=mean0, rstd0=rstd0, kpm=kpm, seed=seed, pd=pd, pa=pa, layers=[])
+        for l in range(self.L):
+            k = f'l{l}.'
+            st = 8 * (l + 1)
+            _, qkv, _ = K.linear_fwd(xb, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), M, 3 * D, D, want_bf16=True)
+            ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, S, S, D // H, kpm,
+                                  Drop(pa, seed, st))
+            s1, _, _ = K.linear_fwd(ctx, W.s(k + 'ao_w'), W.p(k + 'ao_b'), M, D, D, want_f32=True, residual=x, drop=Drop(pd, seed, st + 1))
+            x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p(k + 'ao_ln.w'), W.p(k + 'ao_ln.b'), M, D, want_bf16=True, eps=self.eps)
+            _, g, a = K.linear_fwd(x1b, W.s(k + 'i_w'), W.p(k + 'i_b'), M, I, D, want_bf16=True, want_pre=True, act=K.ACT_GELU)
+            s2, _, _ = K.linear_fwd(g, W.s(k + 'o_w'), W.p(k + 'o_b'), M, D, I, want_f32=True, residual=x1, drop=Drop(pd, seed, st + 2))
+            x2, x2b, m2, r2 = K.layernorm_fwd(s2, W.p(k + 'o_ln.w'), W.p(k + 'o_ln.b'), M, D, want_bf16=True, eps=self.eps)
+            saved['layers'].append((xb, qkv, ctx, s1, m1, r1, x1b, a, g, s2, m2, r2))
+            x, xb = x2, x2b
+        return x.view(B, S, D), saved
+
+    def backward(self, saved, dout):
+        W, D, H, I = self.W, self.D, self.H, self.I
+        B, S, seed, pd, pa, kpm = saved['B'], saved['S'], saved['seed'], saved['pd'], saved['pa'], saved['kpm']
+        M = B * S
+        G = {}
+        dx = dout.reshape(M, D).contiguous().float()
+        dev = dx.device
+        for l in reversed(range(self.L)):
+            k = f'l{l}.'
+            st = 8 * (l + 1)
+            xb, qkv, ctx, s1, m1, r1, x1b, a, g, s2, m2, r2 = saved['layers'][l]
+            # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g))
+            ds2, ds2b, G[k + 'o_ln.w'], G[k + 'o_ln.b'] = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True,
+                                                                          drop=Drop(pd, seed, st + 2), drop_mode=1)
+            _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU)
+            G[k + 'o_w'] = K.linear_dw(ds2b, g, M, D, I)
+            G[k + 'o_b'] = K.colsum_bf16(ds2b, M, D)
+            dx1, _ = K.linear_dx(da, W.s(k + 'i_w'), M, I, D, want_f32=True, residual=ds2)
+            G[k + 'i_w'] = K.linear_dw(da, x1b, M, I, D)
+            G[k + 'i_b'] = K.colsum_bf16(da, M, I)
+            # attention-output LayerNorm:  x1 = LN(s1),  s1 = x + drop(dense(ctx))
+            ds1, ds1b, G[k + 'ao_ln.w'], G[k + 'ao_ln.b'] = K.layernorm_bwd(dx1, s1, m1, r1, W.p(k + 'ao_ln.w'), M, D, want_bf16=True,
+                                                                            drop=Drop(pd, seed, st + 1), drop_mode=1)
+            _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
+            G[k + 'ao_w'] = K.linear_dw(ds1b, ctx, M, D, D)
+            G[k + 'ao_b'] = K.colsum_bf16(ds1b, M, D)
+            dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+            K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, S, S, D // H,
+                            dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, kpm, Drop(pa, seed, st))
+            dx, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True, residual=ds1)
+            G[k + 'qkv_w'] = K.linear_dw(dqkv, xb, M, 3 * D, D)
+            G[k + 'qkv_b'] = K.colsum_bf16(dqkv, M, 3 * D)
+        du, _, G['emb_ln.w'], G['emb_ln.b'] = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
+                                                              drop=Drop(pd, seed, 1), drop_mode=2)
+        G['word'] = torch.zeros_like(W.p('word'))
+        G['pos'] = torch.zeros_like(W.p('pos'))
+        G['type'] = torch.zeros_like(W.p('type'))
+        K.roberta_embed_bwd(du, saved['ids'], saved['pos_ids'], G['word'], G['pos'], G['type'], B, S, D, self.pad)
+        return G
+
+
+# ==================================================================================================================
+# CrossModalAttention fusion layer (post-LN: self-MHA, cross-MHA, FFN)       reference: vqa_model.py:237-311
+# ==================================================================================================================
+
+class CrossModalAttentionRunner:
+    def __init__(self, W, D, heads, dropout, eps=1e-5):
+        self.W, self.D, self.H, self.pd, self.eps = W, D, heads, dropout, eps
+
+    def forward(self, query, key_value, query_mask, kv_mask, training):
+        """query [B,Sq,D] fp32, key_value [B,Skv,D] fp32; masks bool [B,S] (True = ignore) or None."""
+        W, D, H = self.W, self.D, self.H
+        B, Sq, _ = query.shape
+        Skv = key_value.shape[1]
+        M, Mv, Dh, I = B * Sq, B * Skv, D // H, 4 * D
+        seed = new_seed() if training else 0
+        pd = self.pd if training else 0.0
+        x = query.reshape(M, D).contiguous().float()
+        xb = K.cast_bf16(x)
+        kvb = K.cast_bf16(key_value.reshape(Mv, D).contiguous().float())
+        qm, km = _mask_u8(query_mask), _mask_u8(kv_mask)
+        # --- self attention
+        _, qkv, _ = K.linear_fwd(xb, W.s('sa_in_w'), W.p('sa_in_b'), M, 3 * D, D, want_bf16=True)
+        ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh, qm, Drop(pd, seed, 1))
+        s1, _, _ = K.linear_fwd(ctx, W.s('sa_out_w'), W.p('sa_out_b'), M, D, D, want_f32=True, residual=x, drop=Drop(pd, seed, 2))
+        x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p('n1.w'), W.p('n1.b'), M, D, want_bf16=True, eps=self.eps)
+        # --- cross attention: q from text, k/v from vision (rows D: of the packed in_proj)
+        w_in, b_in = W.s('ca_in_w'), W.p('ca_in_b')
+        _, q2, _ = K.linear_fwd(x1b, w_in[:D], b_in[:D], M, D, D, want_bf16=True)
+        _, kv2, _ = K.linear_fwd(kvb, w_in[D:], b_in[D:], Mv, 2 * D, D, want_bf16=True)
+        ctx2 = K.attention_fwd(q2, kv2[:, :D], kv2[:, D:], D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, km, Drop(pd, seed, 3))
+        s2, _, _ = K.linear_fwd(ctx2, W.s('ca_out_w'), W.p('ca_out_b'), M, D, D, want_f32=True, residual=x1, drop=Drop(pd, seed, 4))
+        x2, x2b, m2, r2 = K.layernorm_fwd(s2, W.p('n2.w'), W.p('n2.b'), M, D, want_bf16=True, eps=self.eps)
+        # --- FFN: Linear, GELU, Dropout, Linear, Dropout
+        _, g, a = K.linear_fwd(x2b, W.s('ffn0_w'), W.p('ffn0_b'), M, I, D, want_bf16=True, want_pre=True, act=K.ACT_GELU, drop=Drop(pd, seed, 5))
+        s3, _, _ = K.linear_fwd(g, W.s('ffn3_w'), W.p('ffn3_b'), M, D, I, want_f32=True, residual=x2, drop=Drop(pd, seed, 6))
+        x3, _, m3, r3 = K.layernorm_fwd(s3, W.p('n3.w'), W.p('n3.b'), M, D, eps=self.eps)
+        saved = dict(B=B, Sq=Sq, Skv=Skv, seed=seed, pd=pd, qm=qm, km=km, xb=xb, kvb=kvb, qkv=qkv, ctx=ctx, s1=s1, m1=m1, r1=r1,
+                     x1b=x1b, q2=q2, kv2=kv2, ctx2=ctx2, s2=s2, m2=m2, r2=r2, x2b=x2b, a=a, g=g, s3=s3, m3=m3, r3=r3)
+        return x3.view(B, Sq, D), saved
+
+    def backward(self, saved, dout, need_dkv=True):
+        """Returns (G, dquery [B,Sq,D] fp32, dkey_value [B,Skv,D] fp32 | None)."""
+        W, D, H = self.W, self.D, self.H
+        S = saved
+        B, Sq, Skv, seed, pd = S['B'], S['Sq'], S['Skv'], S['seed'], S['pd']
+        M, Mv, Dh, I = B * Sq, B * Skv, D // H, 4 * D
+        G = {}
+        dx3 = dout.reshape(M, D).contiguous().float()
+        dev = dx3.device
+        ds3, ds3b, G['n3.w'], G['n3.b'] = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), M, D, want_bf16=True,
+                                                          drop=Drop(pd, seed, 6), drop_mode=1)
+        _, da = K.linear_dx(ds3b, W.s('ffn3_w'), M, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5))
+        G['ffn3_w'] = K.linear_dw(ds3b, S['g'], M, D, I)
+        G['ffn3_b'] = K.colsum_bf16(ds3b, M, D)
+        dx2, _ = K.linear_dx(da, W.s('ffn0_w'), M, I, D, want_f32=True, residual=ds3)
+        G['ffn0_w'] = K.linear_dw(da, S['x2b'], M, I, D)
+        G['ffn0_b'] = K.colsum_bf16(da, M, I)
+        # --- cross attention
+        ds2, ds2b, G['n2.w'], G['n2.b'] = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), M, D, want_bf16=True,
+                                                          drop=Drop(pd, seed, 4), drop_mode=1)
+        _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
+        G['ca_out_w'] = K.linear_dw(ds2b, S['ctx2'], M, D, D)
+        G['ca_out_b'] = K.colsum_bf16(ds2b, M, D)
+        dq2 = torch.empty((M, D), dtype=BF16, device=dev)
+        dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
+        kv2 = S['kv2']
+        K.attention_bwd(S['q2'], kv2[:, :D], kv2[:, D:], dctx2, D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, dq2, dkv2[:, :D], dkv2[:, D:],
+                        D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3))
+        w_in = W.s('ca_in_w')
+        dx1, _ = K.linear_dx(dq2, w_in[:D], M, D, D, want_f32=True, residual=ds2)
+        g_in_w = torch.empty((3 * D, D), dtype=F32, device=dev)
+        K.linear_dw(dq2, S['x1b'], M, D, D, out=g_in_w[:D])
+        K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=g_in_w[D:])
+        G['ca_in_w'] = g_in_w
+        g_in_b = torch.empty((3 * D,), dtype=F32, device=dev)
+        K.colsum_bf16(dq2, M, D, out=g_in_b[:D])
+        K.colsum_bf16(dkv2, Mv, 2 * D, out=g_in_b[D:])
+        G['ca_in_b'] = g_in_b
+        dkv = None
+        if need_dkv:
+            dkv, _ = K.linear_dx(dkv2, w_in[D:], Mv, 2 * D, D, want_f32=True)
+            dkv = dkv.view(B, Skv, D)
+        # --- self attention
+        ds1, ds1b, G['n1.w'], G['n1.b'] = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), M, D, want_bf16=True,
+                                                          drop=Drop(pd, seed, 2), drop_mode=1)
+        _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
+        G['sa_out_w'] = K.linear_dw(ds1b, S['ctx'], M, D, D)
+        G['sa_out_b'] = K.colsum_bf16(ds1b, M, D)
+        qkv = S['qkv']
+        dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+        K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh,
+                        dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, S['qm'], Drop(pd, seed, 1))
+        dx, _ = K.linear_dx(dqkv, W.s('sa_in_w'), M, 3 * D, D, want_f32=True, residual=ds1)
+        G['sa_in_w'] = K.linear_dw(dqkv, S['xb'], M, 3 * D, D)
+        G['sa_in_b'] = K.colsum_bf16(dqkv, M, 3 * D)
+        return G, dx.view(B, Sq, D), dkv

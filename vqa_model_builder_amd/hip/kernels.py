@@ -1,0 +1,278 @@
+"""Typed, allocation-aware wrappers over the C ABI (one Python call = one kernel launch on torch's current stream).
+
+PyTorch is plumbing here: it owns device memory (``torch.empty``) and the stream; every byte of arithmetic happens in
+libvqa_hip.so.  All wrappers raise on a non-zero return code.
+"""
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as _l
+
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise HipError(f'{what} failed with code {rc}')
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def L():
+    return _l.load()
+
+
+_gd = _l.VqaGemmDesc()
+_ad = _l.VqaAttnDesc()
+
+
+class Drop:
+    """Dropout site descriptor: probability + (seed, stream) key of the counter RNG."""
+    __slots__ = ('p', 'seed', 'stream')
+
+    def __init__(self, p=0.0, seed=0, stream=0):
+        self.p, self.seed, self.stream = float(p), int(seed), int(stream)
+
+
+NO_DROP = Drop()
+
+
+def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=None, pre_bf16=None, bias=None,
+         residual=None, act_grad_of=None, act=ACT_NONE, act_bwd=ACT_NONE, drop: Drop = NO_DROP, allow_split_k=False,
+         split_k=0, tile_hint=0, ldc_f32=None, ldc_bf16=None, ld_pre=None, ld_res=None, ld_ag=None):
+    d = _gd
+    d.a, d.b = _p(a), _p(b)
+    d.M, d.N, d.K, d.lda, d.ldb, d.a_kc, d.b_kc = M, N, K, lda, ldb, int(a_kc), int(b_kc)
+    d.c_f32, d.ldc_f32 = _p(out_f32), (ldc_f32 or N)
+    d.c_bf16, d.ldc_bf16 = _p(out_bf16), (ldc_bf16 or N)
+    d.pre_bf16, d.ld_pre = _p(pre_bf16), (ld_pre or N)
+    d.bias = _p(bias)
+    d.residual, d.ld_res = _p(residual), (ld_res or N)
+    d.act_grad_of, d.ld_ag = _p(act_grad_of), (ld_ag or N)
+    d.act, d.act_bwd, d.alpha = act, act_bwd, 1.0
+    d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
+    d.split_k, d.allow_split_k, d.tile_hint = split_k, int(allow_split_k), tile_hint
+    _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
+
+
+# ---- the three linear-layer products (torch Linear weight [N,K]) ---------------------------------------------
+
+def linear_fwd(x_bf16, w_bf16, bias, M, N, K, *, want_f32=False, want_bf16=False, want_pre=False, act=ACT_NONE,
+               residual=None, drop: Drop = NO_DROP, lda=None):
+    """y = drop(act(x W^T + b)) + residual.  Returns (y_f32|None, y_bf16|None, pre_bf16|None)."""
+    dev = x_bf16.device
+    yf = torch.empty((M, N), dtype=F32, device=dev) if want_f32 else None
+    yb = torch.empty((M, N), dtype=BF16, device=dev) if want_bf16 else None
+    pre = torch.empty((M, N), dtype=BF16, device=dev) if want_pre else None
+    gemm(x_bf16, w_bf16, M, N, K, lda or K, K, True, True, out_f32=yf, out_bf16=yb, pre_bf16=pre, bias=bias,
+         residual=residual, act=act, drop=drop)
+    return yf, yb, pre
+
+
+def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, residual=None, act_grad_of=None,
+              act_bwd=ACT_NONE, drop: Drop = NO_DROP, ldw=None, ldy=None):
+    """dx[M,K] = (dy[M,N] W[N,K]) * act'(act_grad_of) * dropmask + residual."""
+    dev = dy_bf16.device
+    of = torch.empty((M, K), dtype=F32, device=dev) if want_f32 else None
+    ob = torch.empty((M, K), dtype=BF16, device=dev) if want_bf16 else None
+    gemm(dy_bf16, w_bf16, M, K, N, ldy or N, ldw or K, True, False, out_f32=of, out_bf16=ob, residual=residual,
+         act_grad_of=act_grad_of, act_bwd=act_bwd, drop=drop)
+    return of, ob
+
+
+def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None):
+    """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path)."""
+    if out is None:
+        out = torch.empty((N, K), dtype=F32, device=dy_bf16.device)
+    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True)
+    return out
+
+
+def colsum_bf16(x, M, N, ld=None, out=None):
+    if out is None:
+        out = torch.empty((N,), dtype=F32, device=x.device)
+    _chk(L().vqa_colsum_bf16(_p(x), M, N, ld or N, _p(out), _stream()), 'vqa_colsum_bf16')
+    return out
+
+
+def colsum_f32(x, M, N, ld=None, out=None):
+    if out is None:
+        out = torch.empty((N,), dtype=F32, device=x.device)
+    _chk(L().vqa_colsum_f32(_p(x), M, N, ld or N, _p(out), _stream()), 'vqa_colsum_f32')
+    return out
+
+
+def cast_bf16(x_f32, out=None):
+    x_f32 = x_f32.contiguous()
+    if out is None:
+        out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+    _chk(L().vqa_cast_f32_bf16(_p(x_f32), _p(out), x_f32.numel(), _stream()), 'vqa_cast_f32_bf16')
+    return out
+
+
+def cast_f32(x_bf16):
+    out = torch.empty(x_bf16.shape, dtype=F32, device=x_bf16.device)
+    _chk(L().vqa_cast_bf16_f32(_p(x_bf16), _p(out), x_bf16.numel(), _stream()), 'vqa_cast_bf16_f32')
+    return out
+
+
+def cast_multi(jobs_dev, njobs, max_n):
+    _chk(L().vqa_cast_multi(_p(jobs_dev), njobs, max_n, _stream()), 'vqa_cast_multi')
+
+
+def add_f32(a, b, want_f32=True, want_bf16=False):
+    y = torch.empty_like(a) if want_f32 else None
+    yb = torch.empty(a.shape, dtype=BF16, device=a.device) if want_bf16 else None
+    _chk(L().vqa_add_f32(_p(a), _p(b), _p(y), _p(yb), a.numel(), _stream()), 'vqa_add_f32')
+    return y, yb
+
+
+def gather_rows(src, idx_i32, n, D, ld_src=None, want_f32=False, want_bf16=True):
+    dst = torch.empty((n, D), dtype=F32, device=src.device) if want_f32 else None
+    dstb = torch.empty((n, D), dtype=BF16, device=src.device) if want_bf16 else None
+    _chk(L().vqa_gather_rows_f32(_p(src), _p(idx_i32), _p(dst), _p(dstb), n, D, ld_src or D, _stream()), 'vqa_gather_rows_f32')
+    return dst, dstb
+
+
+# ---- LayerNorm ------------------------------------------------------------------------------------------------
+
+def layernorm_fwd(x, gamma, beta, rows, cols, *, add=None, want_f32=True, want_bf16=False, eps=1e-5, drop: Drop = NO_DROP):
+    dev = x.device
+    y = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
+    yb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
+    mean = torch.empty((rows,), dtype=F32, device=dev)
+    rstd = torch.empty((rows,), dtype=F32, device=dev)
+    _chk(L().vqa_layernorm_fwd(_p(x), _p(add), _p(gamma), _p(beta), _p(y), _p(yb), _p(mean), _p(rstd), rows, cols, eps,
+                               drop.p, drop.seed, drop.stream, _stream()), 'vqa_layernorm_fwd')
+    return y, yb, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=True, want_bf16=False, want_affine=True,
+                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None):
+    dev = dy.device
+    dx = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
+    dxb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
+    ws = None
+    if want_affine:
+        if dgamma is None:
+            dgamma = torch.empty((cols,), dtype=F32, device=dev)
+        if dbeta is None:
+            dbeta = torch.empty((cols,), dtype=F32, device=dev)
+        ws = torch.empty((L().vqa_layernorm_bwd_ws_floats(cols),), dtype=F32, device=dev)
+    _chk(L().vqa_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb), _p(dgamma), _p(dbeta),
+                               _p(ws), rows, cols, drop.p, drop.seed, drop.stream, drop_mode, _stream()), 'vqa_layernorm_bwd')
+    return dx, dxb, dgamma, dbeta
+
+
+# ---- attention ---------------------------------------------------------------------------------------------------
+
+def attention_fwd(q, k, v, ldq, ldk, ldv, B, H, Sq, Skv, Dh, mask_u8=None, drop: Drop = NO_DROP, out=None):
+    if out is None:
+        out = torch.empty((B * Sq, H * Dh), dtype=BF16, device=q.device)
+    d = _ad
+    d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), _p(out)
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, H * Dh
+    d.B, d.H, d.Sq, d.Skv, d.Dh = B, H, Sq, Skv, Dh
+    d.key_padding_mask, d.scale = _p(mask_u8), 0.0
+    d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
+    d.d_o = d.dq = d.dk = d.dv = None
+    _chk(L().vqa_attention_fwd(C.byref(d), _stream()), 'vqa_attention_fwd')
+    return out
+
+
+def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, lddq, lddk, lddv, mask_u8=None,
+                  drop: Drop = NO_DROP):
+    d = _ad
+    d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), None
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, H * Dh
+    d.B, d.H, d.Sq, d.Skv, d.Dh = B, H, Sq, Skv, Dh
+    d.key_padding_mask, d.scale = _p(mask_u8), 0.0
+    d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
+    d.d_o, d.ldd_o = _p(d_o), H * Dh
+    d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = _p(dq), _p(dk), _p(dv), lddq, lddk, lddv
+    _chk(L().vqa_attention_bwd(C.byref(d), _stream()), 'vqa_attention_bwd')
+
+
+# ---- CLIP / RoBERTa front ends ------------------------------------------------------------------------------------
+
+def patchify(pixels, ps):
+    B, Cc, H, W = pixels.shape
+    out = torch.empty((B * (H // ps) * (W // ps), Cc * ps * ps), dtype=BF16, device=pixels.device)
+    _chk(L().vqa_patchify_bf16(_p(pixels), _p(out), B, Cc, H, W, ps, _stream()), 'vqa_patchify_bf16')
+    return out
+
+
+def clip_assemble(E, cls, pos, B, P, D):
+    u = torch.empty((B * (P + 1), D), dtype=F32, device=E.device)
+    _chk(L().vqa_clip_assemble(_p(E), _p(cls), _p(pos), _p(u), B, P, D, _stream()), 'vqa_clip_assemble')
+    return u
+
+
+def clip_assemble_bwd(du, B, P, D, dcls, dpos):
+    dE = torch.empty((B * P, D), dtype=BF16, device=du.device)
+    _chk(L().vqa_clip_assemble_bwd(_p(du), _p(dE), _p(dcls), _p(dpos), B, P, D, _stream()), 'vqa_clip_assemble_bwd')
+    return dE
+
+
+def roberta_embed_fwd(ids, word, pos, type0, B, S, D, pad_id=1):
+    pos_ids = torch.empty((B, S), dtype=torch.int32, device=ids.device)
+    u = torch.empty((B * S, D), dtype=F32, device=ids.device)
+    _chk(L().vqa_roberta_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(pos_ids), _p(u), B, S, D, pad_id, _stream()),
+         'vqa_roberta_embed_fwd')
+    return u, pos_ids
+
+
+def roberta_embed_bwd(du, ids, pos_ids, dword, dpos, dtype0, B, S, D, pad_id=1):
+    _chk(L().vqa_roberta_embed_bwd(_p(du), _p(ids), _p(pos_ids), _p(dword), _p(dpos), _p(dtype0), B, S, D, pad_id, _stream()),
+         'vqa_roberta_embed_bwd')
+
+
+# ---- loss ------------------------------------------------------------------------------------------------------------
+
+def ce_argmax_fwd(logits, labels, B, Cn):
+    dev = logits.device
+    row_loss = torch.empty((B,), dtype=F32, device=dev)
+    loss = torch.empty((), dtype=F32, device=dev)
+    pred = torch.empty((B,), dtype=torch.int64, device=dev)
+    lse = torch.empty((B,), dtype=F32, device=dev)
+    _chk(L().vqa_softmax_ce_argmax_fwd(_p(logits), Cn, _p(labels), _p(row_loss), _p(loss) if labels is not None else None,
+                                       _p(pred), _p(lse), B, Cn, _stream()), 'vqa_softmax_ce_argmax_fwd')
+    return (loss if labels is not None else None), pred, lse
+
+
+def ce_bwd(logits, labels, lse, dloss, B, Cn, want_f32=True, want_bf16=False):
+    dev = logits.device
+    dl = torch.empty((B, Cn), dtype=F32, device=dev) if want_f32 else None
+    dlb = torch.empty((B, Cn), dtype=BF16, device=dev) if want_bf16 else None
+    _chk(L().vqa_softmax_ce_bwd(_p(logits), Cn, _p(labels), _p(lse), _p(dloss), _p(dl), _p(dlb), B, Cn, _stream()),
+         'vqa_softmax_ce_bwd')
+    return dl, dlb
+
+
+# ---- misc ---------------------------------------------------------------------------------------------------------------
+
+def dropout_f32(x, drop: Drop, want_f32=True, want_bf16=False):
+    y = torch.empty_like(x) if want_f32 else None
+    yb = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
+    _chk(L().vqa_dropout_f32(_p(x), _p(y), _p(yb), x.numel(), drop.p, drop.seed, drop.stream, _stream()), 'vqa_dropout_f32')
+    return y, yb
+
+
+def randn(shape, seed, stream, device):
+    out = torch.empty(shape, dtype=F32, device=device)
+    _chk(L().vqa_randn_f32(_p(out), out.numel(), seed, stream, _stream()), 'vqa_randn_f32')
+    return out

@@ -1,0 +1,99 @@
+"""ctypes binding of libvqa_hip.so (include/vqa_hip.h).  Fails loudly when the HIP library is missing:
+there is no CPU or eager-PyTorch fallback anywhere on the product path."""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libvqa_hip.so')
+
+vp, i32, f32, u64, u32, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
+
+
+class VqaGemmDesc(C.Structure):
+    _fields_ = [('a', vp), ('b', vp), ('M', i32), ('N', i32), ('K', i32), ('lda', i32), ('ldb', i32),
+                ('a_kc', i32), ('b_kc', i32),
+                ('c_f32', vp), ('ldc_f32', i32), ('c_bf16', vp), ('ldc_bf16', i32),
+                ('pre_bf16', vp), ('ld_pre', i32), ('bias', vp), ('residual', vp), ('ld_res', i32),
+                ('act_grad_of', vp), ('ld_ag', i32), ('act', i32), ('act_bwd', i32), ('alpha', f32),
+                ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32),
+                ('split_k', i32), ('allow_split_k', i32), ('tile_hint', i32)]
+
+
+class VqaAttnDesc(C.Structure):
+    _fields_ = [('q', vp), ('k', vp), ('v', vp), ('o', vp), ('ldq', i32), ('ldk', i32), ('ldv', i32), ('ldo', i32),
+                ('B', i32), ('H', i32), ('Sq', i32), ('Skv', i32), ('Dh', i32), ('key_padding_mask', vp),
+                ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32),
+                ('d_o', vp), ('ldd_o', i32), ('dq', vp), ('dk', vp), ('dv', vp),
+                ('lddq', i32), ('lddk', i32), ('lddv', i32)]
+
+
+class VqaAdamWDesc(C.Structure):
+    _fields_ = [('param', vp), ('grad', vp), ('exp_avg', vp), ('exp_avg_sq', vp), ('param_bf16', vp), ('n', u64),
+                ('lr', f32), ('beta1', f32), ('beta2', f32), ('eps', f32), ('weight_decay', f32),
+                ('bias_correction1', f32), ('bias_correction2', f32), ('grad_scale', vp)]
+
+
+# name -> (restype, argtypes); must list every symbol include/vqa_hip.h declares (tests check this)
+SIGNATURES = {
+    'vqa_abi_version': (i32, []),
+    'vqa_gemm_bf16': (i32, [C.POINTER(VqaGemmDesc), vp]),
+    'vqa_set_gemm_use_tr': (None, [i32]),
+    'vqa_cast_f32_bf16': (i32, [vp, vp, sz, vp]),
+    'vqa_cast_multi': (i32, [vp, i32, u64, vp]),
+    'vqa_cast_bf16_f32': (i32, [vp, vp, sz, vp]),
+    'vqa_colsum_bf16': (i32, [vp, i32, i32, i32, vp, vp]),
+    'vqa_colsum_f32': (i32, [vp, i32, i32, i32, vp, vp]),
+    'vqa_add_f32': (i32, [vp, vp, vp, vp, sz, vp]),
+    'vqa_gather_rows_f32': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_patchify_bf16': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'vqa_clip_assemble': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_clip_assemble_bwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, u32, vp]),
+    'vqa_layernorm_bwd_ws_floats': (sz, [i32]),
+    'vqa_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, u32, i32, vp]),
+    'vqa_attention_fwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
+    'vqa_attention_bwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
+    'vqa_roberta_embed_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'vqa_roberta_embed_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'vqa_softmax_ce_argmax_fwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_softmax_ce_bwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_router_gate_fwd': (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_router_gate_bwd': (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_router_topk_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_router_topk_bwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_router_aux_loss': (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
+    'vqa_moe_expert_tokens': (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    'vqa_moe_scatter_add': (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_moe_combine_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_moe_route_weight_grad': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_randn_f32': (i32, [vp, u64, u64, u32, vp]),
+    'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
+    'vqa_adamw_step': (i32, [C.POINTER(VqaAdamWDesc), vp]),
+    'vqa_sumsq_f32': (i32, [vp, u64, vp, vp]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load(path: str = None):
+    """Loads the shared library and types every entry point.  Raises HipLibraryMissing if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipLibraryMissing(
+            f'{p} not found: build it with `python -m vqa_model_builder_amd.csrc.build` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.')
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
