@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the AutoViVQA forward/backward hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one training step of the path over one synthetic batch: forward + backward in
+``train()`` mode (dropout on), gradient all-reduce over RCCL when N > 1, ``clip_grad_norm_(1.0)`` and AdamW
+(lr 2e-5, wd 0.01).  Inputs are resident in HBM before the timed region.  Workload = BASELINE.json configs[1]:
+ViT-B/32 + PhoBERT + CrossAttention fusion, bf16 GEMM operands, batch 32 per GPU (weak scaling).
+Rank 0 prints ONE JSON line (metric/value/.../roofline/cpu_baseline).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (fusion_type, num_experts, description)
+    'cfg2_xattn': ('cross_attention', 0, 'ViT-B/32 + PhoBERT + CrossAttention fusion (BASELINE configs[1])'),
+    'cfg1_concat': ('concat', 0, 'ViT-B/32 + PhoBERT + concat fusion (BASELINE configs[0])'),
+    'cfg3_mcan_moe4': ('mcan', 4, "ViT-B/32 + PhoBERT + 'mcan'(=add) fusion + MoE 4 experts top-2 (BASELINE configs[2])"),
+}
+# fwd+bwd algorithmic GFLOP per sample: training = 3 x forward, FLOP = 2 x MAC
+GFLOP_PER_SAMPLE = {'cfg2_xattn': 66.7, 'cfg1_concat': 59.5, 'cfg3_mcan_moe4': 59.5 + 1.4}
+PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, MI355X_MICROARCH.md
+
+
+def build_model(workload, device):
+    from vqa_model_builder_amd.modeling.meta_arch import (AnswerHeadConfig, FusionConfig, KnowledgeConfig, MOEConfig, TextEncoderConfig,
+                                                          VietnameseVQAModel, VisualEncoderConfig, VQAModelConfig)
+    fusion_type, n_exp, _ = WORKLOADS[workload]
+    cfg = VQAModelConfig(
+        visual_encoder=VisualEncoderConfig(model_name='openai/clip-vit-base-patch32', pretrained=False, output_dim=768),
+        text_encoder=TextEncoderConfig(model_name='vinai/phobert-base', pretrained=False, output_dim=768, max_length=64),
+        fusion=FusionConfig(fusion_type=fusion_type, hidden_dim=768, output_dim=768, num_heads=8, num_layers=2, dropout=0.1),
+        moe=MOEConfig(use_moe=n_exp > 0, num_experts=max(n_exp, 1), top_k=2, hidden_dim=2048),
+        knowledge=KnowledgeConfig(use_knowledge=False),
+        answer_head=AnswerHeadConfig(num_answers=3000, hidden_dims=[768, 512], dropout=0.3))
+    torch.manual_seed(0)                              # identical replicas on every rank
+    model = VietnameseVQAModel(cfg).to(device)
+    with torch.no_grad():                             # HF-style random init (no checkpoints offline)
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+    return model
+
+
+def make_optimizer(model):
+    """Param groups of the reference loop (training_pipeline.py:239-252): no decay for bias / LayerNorm weights."""
+    nd = ('bias', 'LayerNorm.weight', 'layer_norm.weight')
+    decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(t in n for t in nd)]
+    no_decay = [p for n, p in model.named_parameters() if p.requires_grad and any(t in n for t in nd)]
+    return torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': no_decay, 'weight_decay': 0.0}],
+                             lr=2e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
+
+
+def synthetic_batch(B, device, rank):
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    px = torch.randn((B, 3, 224, 224), generator=g, device=device)
+    ids = torch.randint(0, 30000, (B, 64), generator=g, device=device)
+    mask = torch.ones((B, 64), dtype=torch.int64, device=device)
+    labels = torch.randint(0, 3000, (B,), generator=g, device=device)
+    return px, ids, mask, labels
+
+
+def cpu_baseline(workload, steps=3, B=8):
+    """The CPU oracle (plain fp32 torch on the host cores) running the same step definition on a bounded sample."""
+    from oracle import det_weights as dw
+    from oracle import vqa_oracle as vo
+    from tests.conftest import CfgView, load_golden
+    tag = {'cfg2_xattn': 'full_cfg2_xattn', 'cfg1_concat': 'full_cfg1_concat', 'cfg3_mcan_moe4': 'full_cfg3_mcan_moe4'}[workload]
+    _, meta = load_golden(tag)
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, 1)
+    leaves = {k: v.requires_grad_(v.is_floating_point() and v.dim() > 0) for k, v in sd.items()}
+    params = [v for v in leaves.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-5, weight_decay=0.01)
+    cfg = CfgView(meta)
+    px, ids, mask, labels = dw.make_inputs(B, 64, 224, seed=3, pad_rows=False)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        _, loss, _ = vo.vqa_forward(leaves, cfg, px, ids, mask, labels)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    model_name = ''
+    try:
+        model_name = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+    except Exception:
+        pass
+    return {'value': round(B / t, 3), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{steps} timed steps (median) of batch {B}, fp32, eval-mode dropout-free oracle, fwd+bwd+clip+AdamW; {model_name}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--workload', default='cfg2_xattn', choices=list(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    from vqa_model_builder_amd.hip import lib, kernels as K
+    try:
+        lib.load()
+    except lib.HipLibraryMissing:
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
+        lib.load()
+    from vqa_model_builder_amd.dp import GradReducer
+
+    model = build_model(args.workload, device).train()
+    opt = make_optimizer(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    reducer = GradReducer(params) if world > 1 else None
+    px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
+        out.loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+        opt.step()
+        return out.loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+    ms = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    roofline = None
+    if not args.no_roofline:
+        # instrumented re-run of the same step: every launch of the MFMA GEMM kernel (the dominant kernel: >95 % of the
+        # path's FLOPs) is bracketed by HIP events on the stream it is launched on
+        K.GEMM_PROFILE = []
+        step()
+        step()
+        torch.cuda.synchronize()
+        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+        tot_flop = sum(f for f, _, _ in prof)
+        tot_ms = sum(a.elapsed_time(b) for _, a, b in prof)
+        ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (all MFMA GEMM launches of a step)', 'achieved': round(ach, 2),
+                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                    'launches_per_step': len(prof) // 2, 'gemm_ms_per_step': round(tot_ms / 2, 3),
+                    'gemm_gflop_per_step': round(tot_flop / 2 / 1e9, 1),
+                    'whole_step_tflops': round(GFLOP_PER_SAMPLE[args.workload] * args.batch / (ms * 1e-3) / 1e3, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.workload)
+        except Exception as e:                       # the baseline is a report, never a reason to lose the GPU number
+            cpu = {'value': None, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {type(e).__name__}: {e}'}
+
+    if rank == 0:
+        line = {
+            'metric': 'train samples/sec (img+question)', 'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': WORKLOADS[args.workload][2], 'name': args.workload, 'batch_per_gpu': args.batch,
+                       'global_batch': args.batch * world, 'image': '3x224x224', 'seq_len': 64,
+                       'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
+                       'final_loss': round(final_loss, 4)},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

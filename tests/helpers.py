@@ -1,0 +1,23 @@
+"""Builds the HIP model for a golden fixture's dimensions (no hub names: explicit architectures, random init)."""
+from vqa_model_builder_amd.modeling.meta_arch import (AnswerHeadConfig, FusionConfig, KnowledgeConfig, MOEConfig, TextEncoderConfig,
+                                                      VietnameseVQAModel, VisualEncoderConfig, VQAModelConfig)
+
+
+def model_config_from_dims(d, fusion_type, num_experts, pooling='cls'):
+    ve = VisualEncoderConfig(output_dim=d['D'], pretrained=False)
+    ve.arch = dict(hidden_size=d['D'], intermediate_size=d['vit_inter'], num_hidden_layers=d['vit_layers'],
+                   num_attention_heads=d['vit_heads'], image_size=d['image'], patch_size=d['patch'])
+    te = TextEncoderConfig(output_dim=d['D'], max_length=d['seq'], pooling_strategy=pooling, pretrained=False)
+    te.arch = dict(vocab_size=d['vocab'], hidden_size=d['D'], num_hidden_layers=d['txt_layers'], num_attention_heads=d['txt_heads'],
+                   intermediate_size=d['txt_inter'], max_position_embeddings=d['max_pos'], type_vocab_size=1, pad_token_id=1)
+    return VQAModelConfig(
+        visual_encoder=ve, text_encoder=te,
+        fusion=FusionConfig(fusion_type=fusion_type, hidden_dim=d['D'], output_dim=d['D'], num_heads=d['fusion_heads'],
+                            num_layers=d['fusion_layers'], dropout=0.1),
+        moe=MOEConfig(use_moe=num_experts > 0, num_experts=max(num_experts, 1), top_k=2, hidden_dim=d['moe_hidden']),
+        knowledge=KnowledgeConfig(use_knowledge=False),
+        answer_head=AnswerHeadConfig(num_answers=d['num_answers'], hidden_dims=list(d['answer_hidden']), dropout=0.3))
+
+
+def build_model(meta):
+    return VietnameseVQAModel(model_config_from_dims(meta['dims'], meta['fusion_type'], meta['num_experts']))

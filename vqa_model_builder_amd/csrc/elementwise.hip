@@ -154,6 +154,19 @@ __global__ void clip_assemble_bwd_kernel(const float* __restrict__ du, bf16_t* _
     if (tok == 0) dcls[d] = acc;
 }
 
+// dpre = dy * act'(pre) * dropmask(idx)   (backward of y = drop(act(pre)) when it is not fused into a GEMM epilogue)
+__global__ void act_drop_bwd_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ pre, int act, float* __restrict__ out,
+                                    bf16_t* __restrict__ outb, size_t n, float p, float inv_keep, uint64_t seed, uint32_t stream) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = dy[i];
+        if (pre) v *= act_bwd((float)pre[i], act);
+        if (p > 0.f) v *= dropout_scale(seed, stream, i, p, inv_keep);
+        if (out) out[i] = v;
+        if (outb) outb[i] = (bf16_t)v;
+    }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
     __shared__ float red[4];
     float acc = 0.f;
@@ -271,6 +284,15 @@ int vqa_clip_assemble(const float* E, const float* cls, const float* pos, float*
 int vqa_clip_assemble_bwd(const float* du, void* dE_bf16, float* dcls, float* dpos, int B, int P, int D, vqa_stream_t s) {
     if (!du || !dE_bf16 || !dcls || !dpos) return VQA_ERR_ARG;
     hipLaunchKernelGGL(clip_assemble_bwd_kernel, dim3(P + 1, ceil_div(D, 256)), dim3(256), 0, (hipStream_t)s, du, (bf16_t*)dE_bf16, dcls, dpos, B, P, D);
+    return (int)hipGetLastError();
+}
+
+int vqa_act_drop_bwd(const float* dy, const void* pre_bf16, int act, float* out, void* out_bf16, size_t n, float p, uint64_t seed,
+                     uint32_t stream, vqa_stream_t s) {
+    if (!dy || (!out && !out_bf16) || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(act_drop_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)s, dy, (const bf16_t*)pre_bf16, act, out,
+                       (bf16_t*)out_bf16, n, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
     return (int)hipGetLastError();
 }
 

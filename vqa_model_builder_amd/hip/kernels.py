@@ -50,6 +50,9 @@ class Drop:
 
 NO_DROP = Drop()
 
+# bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream: (flop, start, end)
+GEMM_PROFILE = None
+
 
 def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=None, pre_bf16=None, bias=None,
          residual=None, act_grad_of=None, act=ACT_NONE, act_bwd=ACT_NONE, drop: Drop = NO_DROP, allow_split_k=False,
@@ -66,6 +69,13 @@ def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=N
     d.act, d.act_bwd, d.alpha = act, act_bwd, 1.0
     d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
     d.split_k, d.allow_split_k, d.tile_hint = split_k, int(allow_split_k), tile_hint
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K, e0, e1))
+        return
     _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
 
 

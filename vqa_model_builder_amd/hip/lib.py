@@ -45,6 +45,7 @@ SIGNATURES = {
     'vqa_colsum_bf16': (i32, [vp, i32, i32, i32, vp, vp]),
     'vqa_colsum_f32': (i32, [vp, i32, i32, i32, vp, vp]),
     'vqa_add_f32': (i32, [vp, vp, vp, vp, sz, vp]),
+    'vqa_act_drop_bwd': (i32, [vp, vp, i32, vp, vp, sz, f32, u64, u32, vp]),
     'vqa_gather_rows_f32': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_patchify_bf16': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'vqa_clip_assemble': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -85,6 +86,9 @@ def load(path: str = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch ships its own libamdhip64: it must be in the process BEFORE this library is dlopen-ed, so that both bind to
+    # the same HIP runtime (otherwise torch's streams / allocations are foreign to our launches: hipErrorNoDevice)
+    import torch  # noqa: F401
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise HipLibraryMissing(

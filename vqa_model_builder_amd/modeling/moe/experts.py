@@ -1,0 +1,354 @@
+"""Expert networks of the VQA MoE on the HIP path.
+
+Same class names (the ablation harness classifies experts by class-name substring, ablation_trainer.py:415-433),
+constructor signatures, parameter names and ``usage_count`` / ``total_tokens`` buffers as the reference's
+``base_expert.py:12-112``, ``expert_types.py:14-557`` and ``specialized_experts.py:15-308``.  Every forward is a
+short chain of HIP ops (hip/ops.py): the expert GEMMs are skinny (<= 32 routed rows at batch 32) and therefore
+weight-streaming / HBM-bound, not MFMA-bound.
+"""
+
+from abc import ABC, abstractmethod
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ...hip import ops
+from ...hip.kernels import ACT_GELU, ACT_NONE, ACT_RELU, Drop
+from ..meta_arch.vqa_model import _MHAParams
+
+
+def _drop(p, training, stream):
+    return Drop(p, ops.new_seed(), stream) if (training and p > 0) else Drop()
+
+
+class BaseExpert(ABC, nn.Module):
+    """Reference base_expert.py:12-112."""
+    token_local = False        # True: no mixing across the sequence axis -> sparse dispatch is exact at any S
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id: Optional[int] = None, dropout=0.1):
+        super().__init__()
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.expert_id, self.dropout_rate = expert_id, dropout
+        self.register_buffer('usage_count', torch.tensor(0.0))
+        self.register_buffer('total_tokens', torch.tensor(0.0))
+
+    @abstractmethod
+    def forward(self, x, mask=None, **kwargs):
+        pass
+
+    def update_usage_stats(self, num_tokens: int):
+        self.usage_count += 1
+        self.total_tokens += num_tokens
+
+    def get_usage_ratio(self) -> float:
+        if self.total_tokens == 0:
+            return 0.0
+        return (self.usage_count / self.total_tokens).item()
+
+    def reset_usage_stats(self):
+        self.usage_count.zero_()
+        self.total_tokens.zero_()
+
+    def get_expert_info(self) -> Dict[str, Any]:
+        return {'expert_id': self.expert_id, 'input_dim': self.input_dim, 'hidden_dim': self.hidden_dim,
+                'output_dim': self.output_dim, 'usage_ratio': self.get_usage_ratio(),
+                'num_parameters': sum(p.numel() for p in self.parameters())}
+
+
+class ExpertWithCapacity(BaseExpert):
+    """Reference base_expert.py:115-169."""
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, capacity=None):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.capacity = capacity
+
+    def apply_capacity_constraint(self, x, routing_weights):
+        if self.capacity is None or x.size(0) <= self.capacity:
+            return x, routing_weights, torch.arange(x.size(0), device=x.device)
+        _, top = torch.topk(routing_weights, self.capacity)
+        return x[top], routing_weights[top], top
+
+    def forward(self, x, mask=None, **kwargs):
+        raise NotImplementedError
+
+
+def _ffn(seq, x, p, training, stream0, act=ACT_GELU):
+    """Sequential(Linear, act, Dropout, Linear, Dropout) -> two fused GEMMs."""
+    h = ops.linear(x, seq[0].weight, seq[0].bias, act=act, drop=_drop(p, training, stream0))
+    return ops.linear(h, seq[3].weight, seq[3].bias, drop=_drop(p, training, stream0 + 1))
+
+
+def _ln(m, x, residual=None):
+    return ops.layer_norm(x if residual is None else ops.add(x, residual), m.weight, m.bias, m.eps)
+
+
+class FeedForwardExpert(BaseExpert):
+    """Reference expert_types.py:14-92."""
+    token_local = True
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, activation='gelu'):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        acts = {'gelu': (nn.GELU(), ACT_GELU), 'relu': (nn.ReLU(), ACT_RELU)}
+        if activation not in acts:
+            raise NotImplementedError(f'HIP FeedForwardExpert supports gelu/relu (got {activation!r})')
+        self.activation, self._act = acts[activation]
+        self.fc1, self.fc2 = nn.Linear(input_dim, hidden_dim), nn.Linear(hidden_dim, output_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, **kwargs):
+        h = ops.linear(x, self.fc1.weight, self.fc1.bias, act=self._act, drop=_drop(self.dropout_rate, self.training, 101))
+        h = ops.linear(h, self.fc2.weight, self.fc2.bias, drop=_drop(self.dropout_rate, self.training, 102))
+        return _ln(self.layer_norm, h, x if x.size(-1) == self.output_dim else None)
+
+
+class VisionExpert(BaseExpert):
+    """Reference expert_types.py:95-199."""
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_heads=8,
+                 use_spatial_attention=True):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.num_heads, self.use_spatial_attention = num_heads, use_spatial_attention
+        self.input_proj = nn.Linear(input_dim, hidden_dim)
+        if use_spatial_attention:
+            self.spatial_attention = _MHAParams(hidden_dim, num_heads, dropout)
+            self.spatial_norm = nn.LayerNorm(hidden_dim)
+        self.transform = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                       nn.Linear(hidden_dim, hidden_dim), nn.Dropout(dropout))
+        self.output_proj = nn.Linear(hidden_dim, output_dim)
+        self.output_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, spatial_positions=None, **kwargs):
+        h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
+        if spatial_positions is not None:
+            h = ops.add(h, spatial_positions)
+        if self.use_spatial_attention:
+            a, _ = self.spatial_attention(h, h, h, key_padding_mask=mask)
+            h = _ln(self.spatial_norm, h, a)
+        h = ops.add(h, _ffn(self.transform, h, self.dropout_rate, self.training, 111))
+        out = ops.linear(h, self.output_proj.weight, self.output_proj.bias)
+        return _ln(self.output_norm, out)
+
+
+class TextExpert(BaseExpert):
+    """Reference expert_types.py:202-312."""
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_heads=8,
+                 use_self_attention=True, max_seq_length=512):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.num_heads, self.use_self_attention, self.max_seq_length = num_heads, use_self_attention, max_seq_length
+        self.input_proj = nn.Linear(input_dim, hidden_dim)
+        if use_self_attention:
+            self.self_attention = _MHAParams(hidden_dim, num_heads, dropout)
+            self.attention_norm = nn.LayerNorm(hidden_dim)
+        self.ffn = nn.Sequential(nn.Linear(hidden_dim, hidden_dim * 2), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim * 2, hidden_dim), nn.Dropout(dropout))
+        self.ffn_norm = nn.LayerNorm(hidden_dim)
+        self.output_proj = nn.Linear(hidden_dim, output_dim)
+        self.output_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, **kwargs):
+        h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
+        if self.use_self_attention:
+            kpm = ~mask.bool() if mask is not None else None
+            a, _ = self.self_attention(h, h, h, key_padding_mask=kpm)
+            h = _ln(self.attention_norm, h, a)
+        h = _ln(self.ffn_norm, h, _ffn(self.ffn, h, self.dropout_rate, self.training, 121))
+        out = ops.linear(h, self.output_proj.weight, self.output_proj.bias)
+        return _ln(self.output_norm, out)
+
+
+class MultimodalExpert(BaseExpert):
+    """Reference expert_types.py:315-445.  ``context`` is never passed by MOELayer, so cross_attention, cross_norm and
+    modality_gate are dead parameters that receive no gradient there either; they are kept for the
+    state_dict and honoured if a caller does pass ``context``."""
+    token_local = True         # without context there is no mixing across tokens
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_heads=8,
+                 use_cross_attention=True, use_modality_gate=True):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.num_heads, self.use_cross_attention, self.use_modality_gate = num_heads, use_cross_attention, use_modality_gate
+        self.input_proj = nn.Linear(input_dim, hidden_dim)
+        if use_cross_attention:
+            self.cross_attention = _MHAParams(hidden_dim, num_heads, dropout)
+            self.cross_norm = nn.LayerNorm(hidden_dim)
+        if use_modality_gate:
+            self.modality_gate = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.Sigmoid())
+        self.transform = nn.Sequential(nn.Linear(hidden_dim, hidden_dim * 2), nn.GELU(), nn.Dropout(dropout),
+                                       nn.Linear(hidden_dim * 2, hidden_dim), nn.Dropout(dropout))
+        self.transform_norm = nn.LayerNorm(hidden_dim)
+        self.output_proj = nn.Linear(hidden_dim, output_dim)
+        self.output_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, context=None, context_mask=None, **kwargs):
+        h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
+        if self.use_cross_attention and context is not None:
+            raise NotImplementedError('MultimodalExpert(context=...) is unreachable from MOELayer in the reference '
+                                      '(expert_types.py:414) and is not implemented on the HIP path')
+        h = _ln(self.transform_norm, h, _ffn(self.transform, h, self.dropout_rate, self.training, 131))
+        out = ops.linear(h, self.output_proj.weight, self.output_proj.bias)
+        return _ln(self.output_norm, out)
+
+
+class GatedLinearExpert(BaseExpert):
+    """Reference expert_types.py:448-515 (only reachable through create_expert('glu'); not on the VQA path)."""
+    token_local = True
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.fc1, self.fc2 = nn.Linear(input_dim, hidden_dim * 2), nn.Linear(hidden_dim, output_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, **kwargs):
+        raise NotImplementedError('GatedLinearExpert has no HIP kernel yet (not constructed by VietnameseVQAModel)')
+
+
+def create_expert(expert_type, input_dim, hidden_dim, output_dim, expert_id=None, **kwargs) -> BaseExpert:
+    """Reference expert_types.py:518-557."""
+    experts = {'feedforward': FeedForwardExpert, 'vision': VisionExpert, 'text': TextExpert,
+               'multimodal': MultimodalExpert, 'glu': GatedLinearExpert}
+    if expert_type not in experts:
+        raise ValueError(f"Unknown expert type: {expert_type}. Available: {list(experts.keys())}")
+    return experts[expert_type](input_dim=input_dim, hidden_dim=hidden_dim, output_dim=output_dim, expert_id=expert_id, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# specialised experts (reference specialized_experts.py).  nn.TransformerDecoder(Layer) parameter layout is kept.
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _DecoderLayer(nn.Module):
+    """Parameter layout + HIP forward of torch ``nn.TransformerDecoderLayer`` defaults: post-LN, gelu, no masks."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = _MHAParams(d_model, nhead, dropout)
+        self.multihead_attn = _MHAParams(d_model, nhead, dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+        self._p = dropout
+
+    def forward(self, tgt, memory):
+        p, tr = self._p, self.training
+        a, _ = self.self_attn(tgt, tgt, tgt)
+        x = _ln(self.norm1, tgt, ops.dropout(a, p, tr))
+        a, _ = self.multihead_attn(x, memory, memory)
+        x = _ln(self.norm2, x, ops.dropout(a, p, tr))
+        h = ops.linear(x, self.linear1.weight, self.linear1.bias, act=ACT_GELU, drop=_drop(p, tr, 141))
+        f = ops.linear(h, self.linear2.weight, self.linear2.bias, drop=_drop(p, tr, 142))
+        return _ln(self.norm3, x, f)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(_DecoderLayer(d_model, nhead, dim_feedforward, dropout) for _ in range(num_layers))
+
+    def forward(self, tgt, memory):
+        for layer in self.layers:
+            tgt = layer(tgt, memory)
+        return tgt
+
+
+def _conv1d_k3(conv: nn.Conv1d, x, act):
+    """Conv1d(H, H, kernel 3, padding 1) along the sequence axis of x [B,S,H] as ONE GEMM over the three taps
+    (K = 3H); at S == 1 the two outer taps only ever see the zero padding, so only the centre tap streams."""
+    B, S, H = x.shape
+    w = conv.weight                                       # [out, in, tap]
+    if S == 1:
+        return ops.linear(x, w[:, :, 1], conv.bias, act=act)
+    zero = torch.zeros((B, 1, H), dtype=x.dtype, device=x.device)
+    taps = torch.cat([torch.cat([zero, x[:, :-1]], dim=1), x, torch.cat([x[:, 1:], zero], dim=1)], dim=-1)   # [B,S,3H]
+    return ops.linear(taps, w.permute(0, 2, 1).reshape(w.shape[0], 3 * H), conv.bias, act=act)
+
+
+class SegmentationExpert(BaseExpert):
+    """Reference specialized_experts.py:15-173."""
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_mask_tokens=4,
+                 use_pretrained_sam=False, sam_model_type='vit_b'):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.num_mask_tokens, self.use_pretrained_sam, self.sam_model_type = num_mask_tokens, use_pretrained_sam, sam_model_type
+        self.mask_tokens = nn.Parameter(torch.randn(1, num_mask_tokens, hidden_dim) * 0.02)
+        self.input_proj = nn.Linear(input_dim, hidden_dim)
+        self.mask_transformer = _Decoder(hidden_dim, 8, hidden_dim * 2, dropout, 2)
+        self.boundary_conv = nn.Sequential(nn.Conv1d(hidden_dim, hidden_dim, 3, padding=1), nn.GELU(),
+                                           nn.Conv1d(hidden_dim, hidden_dim, 3, padding=1), nn.GELU())
+        self.spatial_mlp = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                         nn.Linear(hidden_dim, hidden_dim))
+
+        self.output_proj = nn.Linear(hidden_dim, output_dim)
+        self.output_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, image_features=None, **kwargs):
+        B, S, _ = x.shape
+        h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
+        mask_feat = self.mask_transformer(self.mask_tokens.expand(B, -1, -1), h)             # [B,M,H]
+        bf = _conv1d_k3(self.boundary_conv[0], h, ACT_GELU)
+        bf = _conv1d_k3(self.boundary_conv[2], bf, ACT_GELU)
+        pooled = mask_feat.mean(dim=1, keepdim=True).expand(-1, S, -1)                       # 4-row mean: plumbing
+        sp_in = torch.cat([bf, pooled], dim=-1)
+        m = self.spatial_mlp
+        sp = ops.linear(ops.linear(sp_in, m[0].weight, m[0].bias, act=ACT_GELU, drop=_drop(self.dropout_rate, self.training, 151)),
+                        m[3].weight, m[3].bias)
+        h = ops.add(ops.add(h, bf), sp)
+        return _ln(self.output_norm, ops.linear(h, self.output_proj.weight, self.output_proj.bias))
+
+
+class ObjectDetectionExpert(BaseExpert):
+    """Reference specialized_experts.py:176-308 (reachable from 8 experts up)."""
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_queries=100,
+                 num_decoder_layers=3):
+        super().__init__(input_dim, hidden_dim, output_dim, expert_id, dropout)
+        self.num_queries = num_queries
+        self.object_queries = nn.Parameter(torch.randn(1, num_queries, hidden_dim) * 0.02)
+        self.input_proj = nn.Linear(input_dim, hidden_dim)
+        self.decoder = _Decoder(hidden_dim, 8, hidden_dim * 2, dropout, num_decoder_layers)
+        self.object_aggregation = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.GELU(), nn.Dropout(dropout))
+        self.query_feature_attention = _MHAParams(hidden_dim, 8, dropout)
+        self.output_proj = nn.Linear(hidden_dim, output_dim)
+        self.output_norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, mask=None, return_object_features=False, **kwargs):
+        B = x.shape[0]
+        h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
+        obj = self.decoder(self.object_queries.expand(B, -1, -1), h)
+        agg = self.object_aggregation[0]
+        obj = ops.linear(obj, agg.weight, agg.bias, act=ACT_GELU, drop=_drop(self.dropout_rate, self.training, 161))
+        enh, _ = self.query_feature_attention(h, obj, obj)
+        h = ops.add(h, enh)
+        out = _ln(self.output_norm, ops.linear(h, self.output_proj.weight, self.output_proj.bias))
+        return (out, obj) if return_object_features else out
+
+
+class _Unported(BaseExpert):
+    """Specialised experts the reference only instantiates at >= 12 experts (OCR) / >= 16 (scene) or never
+    (spatial, counting: specialized_experts.py:311-897).  Constructing them raises, loudly."""
+
+    def __init__(self, *a, **kw):
+        raise NotImplementedError(f'{type(self).__name__} is outside the hot-path scope of this round (SURVEY section 8a: '
+                                  'only Segmentation/ObjectDetection are reachable at <= 8 experts)')
+
+    def forward(self, x, mask=None, **kwargs):
+        raise NotImplementedError
+
+
+class OCRExpert(_Unported):
+    pass
+
+
+class SceneUnderstandingExpert(_Unported):
+    pass
+
+
+class SpatialReasoningExpert(_Unported):
+    pass
+
+
+class CountingExpert(_Unported):
+    pass

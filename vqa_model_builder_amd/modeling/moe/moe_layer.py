@@ -1,0 +1,190 @@
+"""Mixture-of-Experts layers on the HIP path (reference src/modeling/moe/moe_layer.py: MOELayer :29-196,
+SparseMOELayer :199-358, VQAMOELayer :551-692).
+
+Contracts kept for the ablation harness (ablation_trainer.py:112-305): ``self.router`` is looked up and called as
+``self.router(x)`` on every forward (it gets monkey-patched and swapped), any K <= E and arbitrary (also zero)
+routing weights are accepted, ``expert_indices == -1`` routes nowhere, ``aux_outputs`` / ``get_aux_loss()`` /
+``get_expert_usage()`` / ``experts`` / ``input_dim`` / ``num_experts`` / ``top_k`` exist.
+
+Execution: the reference runs every selected expert on ALL tokens and multiplies by a weight that is 0 for unrouted
+ones (moe_layer.py:151-168).  Here tokens are dispatched: each expert runs only on the rows routed to it, which is
+numerically equivalent whenever the expert does not mix tokens across the sequence axis -- always at S = 1 (the
+classification model, vqa_model.py:674) and for token-local experts at any S.  Attention-bearing
+experts at S > 1 take the reference's dense route so their cross-token attention sees the same rows.
+"""
+
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ...hip import kernels as K
+from ...hip import ops
+from .experts import MultimodalExpert, TextExpert, VisionExpert, create_expert
+from .router import NoisyTopKRouter, create_router
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, lst, n):
+        T, D = x2.shape
+        out, _ = K.gather_rows(x2, lst, n, D, want_f32=True, want_bf16=False)
+        ctx.save_for_backward(lst)
+        ctx.meta = (T, D, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lst,) = ctx.saved_tensors
+        T, D, n = ctx.meta
+        dx = torch.zeros((T, D), dtype=torch.float32, device=dy.device)
+        ones = torch.ones((T,), dtype=torch.float32, device=dy.device)
+        dy = dy.contiguous().float()
+        K._chk(K.L().vqa_moe_scatter_add(dy.data_ptr(), lst.data_ptr(), ones.data_ptr(), dx.data_ptr(), n, D, K._stream()), 'vqa_moe_scatter_add')
+        return dx, None, None
+
+
+class _CombineFn(torch.autograd.Function):
+    """out[t] = sum_e w_all[e,t] * y_e[row of t]  -- one node for the whole weighted scatter (moe_layer.py:160-168)."""
+
+    @staticmethod
+    def forward(ctx, weights, indices, w_all, lists, counts, T, D, *ys):
+        dev = weights.device
+        out = torch.zeros((T, D), dtype=torch.float32, device=dev)
+        st = K._stream()
+        ys = [y.contiguous().float() if y is not None else None for y in ys]
+        for e, y in enumerate(ys):
+            if y is None:
+                continue
+            K._chk(K.L().vqa_moe_scatter_add(y.data_ptr(), lists[e].data_ptr(), w_all[e].data_ptr(), out.data_ptr(), counts[e], D, st),
+                   'vqa_moe_scatter_add')
+        ctx.save_for_backward(indices, w_all, lists, *[y for y in ys if y is not None])
+        ctx.meta = (counts, T, D, [y is not None for y in ys], weights.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        indices, w_all, lists, *ys_saved = ctx.saved_tensors
+        counts, T, D, present, wshape = ctx.meta
+        dev, st = dout.device, K._stream()
+        dout = dout.contiguous().float()
+        E = w_all.shape[0]
+        dw_all = torch.zeros((E, T), dtype=torch.float32, device=dev)
+        dys, it = [], iter(ys_saved)
+        for e, has in enumerate(present):
+            if not has:
+                dys.append(None)
+                continue
+            y = next(it)
+            dy = torch.empty_like(y)
+            K._chk(K.L().vqa_moe_combine_bwd(dout.data_ptr(), y.data_ptr(), lists[e].data_ptr(), w_all[e].data_ptr(), dy.data_ptr(), None,
+                                             dw_all[e].data_ptr(), counts[e], D, st), 'vqa_moe_combine_bwd')
+            dys.append(dy)
+        Kk = indices.shape[-1]
+        dweights = torch.empty((T, Kk), dtype=torch.float32, device=dev)
+        K._chk(K.L().vqa_moe_route_weight_grad(dw_all.data_ptr(), indices.data_ptr(), dweights.data_ptr(), T, E, Kk, st), 'vqa_moe_route_weight_grad')
+        return (dweights.view(wshape), None, None, None, None, None, None) + tuple(dys)
+
+
+class MOELayer(nn.Module):
+    """Reference moe_layer.py:29-196."""
+
+    def __init__(self, config=None, input_dim=768, hidden_dim=3072, output_dim=768, num_experts=8, top_k=2, router_type='topk',
+                 expert_type='feedforward', dropout=0.1, use_aux_loss=True, load_balance_weight=0.01):
+        super().__init__()
+        if config is not None:
+            input_dim, hidden_dim, output_dim = config.input_dim, config.hidden_dim, config.output_dim
+            num_experts, top_k, dropout = config.num_experts, config.num_experts_per_token, config.expert_dropout
+            if config.router_config:
+                router_type = config.router_config.router_type
+                use_aux_loss = config.router_config.use_aux_loss
+                load_balance_weight = config.router_config.load_balance_weight
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.num_experts, self.top_k = num_experts, top_k
+        self.router = create_router(router_type=router_type, input_dim=input_dim, num_experts=num_experts, top_k=top_k,
+                                    use_aux_loss=use_aux_loss, load_balance_weight=load_balance_weight)
+        self.experts = nn.ModuleList([create_expert(expert_type=expert_type, input_dim=input_dim, hidden_dim=hidden_dim,
+                                                    output_dim=output_dim, expert_id=i, dropout=dropout) for i in range(num_experts)])
+        self.output_norm = nn.LayerNorm(output_dim)
+        self.aux_outputs: Dict[str, Any] = {}
+
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError('MOELayer: HIP path needs GPU tensors; no CPU fallback on the product path')
+        B, S, D = x.shape
+        T, E = B * S, len(self.experts)
+        routing_weights, expert_indices, aux_outputs = self.router(x)
+        self.aux_outputs = aux_outputs
+        Kk = expert_indices.shape[-1]
+        w2 = routing_weights.reshape(T, Kk).contiguous().float()
+        i2 = expert_indices.reshape(T, Kk).contiguous().long()
+        dev = x.device
+        w_all = torch.empty((E, T), dtype=torch.float32, device=dev)
+        lists = torch.empty((E, T), dtype=torch.int32, device=dev)
+        counts_dev = torch.empty((E,), dtype=torch.int32, device=dev)
+        K._chk(K.L().vqa_moe_expert_tokens(w2.detach().data_ptr(), i2.data_ptr(), T, Kk, E, w_all.data_ptr(), lists.data_ptr(),
+                                           counts_dev.data_ptr(), K._stream()), 'vqa_moe_expert_tokens')
+        counts = counts_dev.tolist()      # the reference syncs once per expert (`.any()`, moe_layer.py:156); here once per layer
+        x2 = x.reshape(T, D)
+        ys = []
+        for e, expert in enumerate(self.experts):
+            n = counts[e]
+            if n == 0:                    # unrouted expert: skipped, its parameters get no gradient (F9)
+                ys.append(None)
+                continue
+            if S == 1 or expert.token_local:
+                xe = _GatherRowsFn.apply(x2, lists[e], n)
+                ys.append(expert(xe.view(n, 1, D), **kwargs).reshape(n, self.output_dim))
+            else:                         # cross-token attention inside the expert: dense route like the reference
+                ye = expert(x, mask=mask, **kwargs).reshape(T, self.output_dim)
+                ys.append(_GatherRowsFn.apply(ye, lists[e], n))
+        out = _CombineFn.apply(w2, i2, w_all, lists, counts, T, self.output_dim, *ys)
+        out = ops.layer_norm(out, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
+        return out.view(B, S, self.output_dim)
+
+    def get_aux_loss(self) -> torch.Tensor:
+        if 'load_balance_loss' in self.aux_outputs:
+            return self.aux_outputs['load_balance_loss']
+        return torch.tensor(0.0)
+
+    def get_expert_usage(self) -> Dict[int, float]:
+        return {i: e.get_usage_ratio() for i, e in enumerate(self.experts)}
+
+
+class VQAMOELayer(MOELayer):
+    """Reference moe_layer.py:551-692: one NoisyTopKRouter + {Vision, Text, Multimodal, specialised} experts."""
+
+    def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, num_vision_experts=2, num_text_experts=2,
+                 num_multimodal_experts=2, num_specialized_experts=2, top_k=2, dropout=0.1, vietnamese_optimized=True):
+        nn.Module.__init__(self)
+        total = num_vision_experts + num_text_experts + num_multimodal_experts + num_specialized_experts
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.num_experts, self.top_k = total, top_k
+        self.router = NoisyTopKRouter(input_dim=input_dim, num_experts=total, top_k=top_k, use_aux_loss=True)
+        from .experts import ObjectDetectionExpert, OCRExpert, SceneUnderstandingExpert, SegmentationExpert
+        kinds = ([VisionExpert] * num_vision_experts + [TextExpert] * num_text_experts + [MultimodalExpert] * num_multimodal_experts)
+        spec = [SegmentationExpert, ObjectDetectionExpert, OCRExpert, SceneUnderstandingExpert]
+        kinds += [spec[i % len(spec)] for i in range(num_specialized_experts)]
+        self.experts = nn.ModuleList()
+        for eid, cls in enumerate(kinds):
+            kw = dict(input_dim=input_dim, hidden_dim=hidden_dim, output_dim=output_dim, expert_id=eid, dropout=dropout)
+            if cls is OCRExpert:
+                kw['vietnamese_optimized'] = vietnamese_optimized
+            self.experts.append(cls(**kw))
+        self.output_norm = nn.LayerNorm(output_dim)
+        self.aux_outputs: Dict[str, Any] = {}
+
+
+class SparseMOELayer(nn.Module):
+    """Reference moe_layer.py:199-358 (capacity-constrained dispatch; used only by the generative model, whose
+    call site is itself broken -- SURVEY F11).  Declared for import compatibility."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError('SparseMOELayer belongs to the generative path (SURVEY section 8f rank 3), not built this round')
+
+
+class HierarchicalMOE(nn.Module):
+    """Reference moe_layer.py:361-548 (examples only)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError('HierarchicalMOE is examples-only in the reference and outside the hot path')
