@@ -55,6 +55,7 @@ typedef struct VqaGemmDesc {
 } VqaGemmDesc;
 int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream);
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
+void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */
 
 /* ---- elementwise / layout --------------------------------------------------------------------------------- */
 /* fp32 -> bf16 (weights shadow, activations); n elements */
@@ -114,6 +115,7 @@ typedef struct VqaAttnDesc {
     void* dq; void* dk; void* dv; int lddq, lddk, lddv;
 } VqaAttnDesc;
 int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s);
+void vqa_set_attention_mfma(int on);       /* 1 (default): MFMA kernel for Sq,Skv <= 64, Dh in {32,64,96,128}; 0: generic kernel only */
 int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s);
 
 /* ---- RoBERTa embeddings (HF RobertaEmbeddings: word + type0 + pad-aware positions, LN) --------------------- */

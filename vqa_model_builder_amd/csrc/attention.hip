@@ -188,9 +188,19 @@ constexpr size_t LDS_MAX = 160 * 1024 - 512;
 
 }  // namespace
 
+int vqa_attention_mfma_fwd(const VqaAttnDesc* d, hipStream_t s);     // attention_mfma.hip; -1 = shape not covered
+int vqa_attention_mfma_bwd(const VqaAttnDesc* d, hipStream_t s);
+static bool g_attn_mfma = true;
+
 extern "C" {
 
+void vqa_set_attention_mfma(int on) { g_attn_mfma = on != 0; }
+
 int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s) {
+    if (g_attn_mfma && d && d->q && d->k && d->v && d->o && d->B > 0 && d->H > 0) {
+        const int rc = vqa_attention_mfma_fwd(d, (hipStream_t)s);
+        if (rc >= 0) return rc;
+    }
     AttnArgs a;
     int rc = fill_args(d, a, false);
     if (rc) return rc;
@@ -211,6 +221,10 @@ int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s) {
 }
 
 int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s) {
+    if (g_attn_mfma && d && d->q && d->k && d->v && d->d_o && d->dq && d->dk && d->dv && d->B > 0 && d->H > 0) {
+        const int rc = vqa_attention_mfma_bwd(d, (hipStream_t)s);
+        if (rc >= 0) return rc;
+    }
     AttnArgs a;
     int rc = fill_args(d, a, true);
     if (rc) return rc;

@@ -47,13 +47,13 @@ __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + (
 // RC tile: [64][ROWS] bf16 (ROWS*2-byte rows); 32-B (two-chunk) blocks are kept whole, block index XORed with a
 // key of the k-row so that the 8 k-rows one half-wave touches in a ds_read_b64_tr_b16 hit distinct banks.
 template <int ROWS>
-__device__ __forceinline__ int rc_off(int krow, int chunk) {
-    int key;
-    if (ROWS >= 128) key = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
-    else if (ROWS == 64) key = (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
-    else key = ((krow >> 3) & 1) << 1;
-    return krow * (ROWS * 2) + ((chunk ^ key) << 4);
+__device__ __forceinline__ int rc_key(int krow) {
+    if (ROWS >= 128) return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
+    else if (ROWS == 64) return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
+    else return ((krow >> 3) & 1) << 1;
 }
+template <int ROWS>
+__device__ __forceinline__ int rc_off(int krow, int chunk) { return krow * (ROWS * 2) + ((chunk ^ rc_key<ROWS>(krow)) << 4); }
 
 template <int ROWS, bool KC>
 struct Stage {
@@ -130,6 +130,58 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int 
     }
 }
 
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane) {
+    // lane holds C[m][n..n+3], m = m_base + 16*i + (lane&15), n = n_base + 16*j + 4*(lane>>4)
+    const bool splitk = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_base + 16 * i + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + 16 * j + 4 * (lane >> 4);
+            if (n >= p.N) continue;                       // N % 4 == 0 is enforced on the host
+            f32x4 v = acc[i][j] * p.alpha;
+            if (splitk) {
+                float* dst = p.c_f32 + (size_t)m * p.ldc_f32 + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                continue;
+            }
+            if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
+            if (p.act_grad_of) {
+                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
+            }
+            if (p.pre_bf16) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+            }
+            if (p.act != ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+            }
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
+            }
+            if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
+            if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
+            if (p.c_bf16) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool USE_TR>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
@@ -201,54 +253,156 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = m0 + wm*WTM + 16*i + (lane&15), n = n0 + wn*WTN + 16*j + 4*(lane>>4)
-    const bool splitk = gridDim.z > 1;
+    gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+// ================================================================================================================
+// v1: LDS-DMA pipeline.  Same tiles / fragments / epilogue, but operand tiles travel HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging), 4 LDS stages of BK = 32, three tiles in flight behind COUNTED
+// s_waitcnt vmcnt(N) and raw s_barrier (never __syncthreads(): it would drain the DMA queue).  The LDS image of a DMA is
+// lane-linear (wave-uniform base + lane*16 B), so the bank-conflict swizzle is applied to each lane's SOURCE address
+// and undone by the same XOR on the fragment reads.  Ragged edges: rows are clamped (their results are never stored),
+// k beyond K reads a zero page.
+// ================================================================================================================
+constexpr int BK1 = 32;
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
+
+// KC tile [ROWS][32] bf16: 64-B rows = 4 chunks, 4 rows per 256-B bank row.  ds_read_b128 is served in the lane groups
+// {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32): one group reads rows {0-3,12-15} at chunk c and rows {4-11} at chunk c^1,
+// so the XOR key must separate (row>>2) in {0,3} from {1,2}: key = ((row>>3)&1)<<1  (PMC: SQ_LDS_BANK_CONFLICT = 0).
+__device__ __forceinline__ int kc1_key(int row) { return ((row >> 3) & 1) << 1; }
+__device__ __forceinline__ int kc1_off(int row, int chunk) { return row * 64 + ((chunk ^ kc1_key(row)) << 4); }
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int ROWS, bool KC>
+__device__ __forceinline__ void issue_tile(char* lds_tile, const bf16_t* __restrict__ g, int ld, int row0, int R, int k0, int Kend,
+                                           int wave, int lane) {
+    constexpr int INSTR = ROWS * 4 / 64;        // 1-KiB wave-instructions per tile
+    constexpr int PER_WAVE = INSTR / 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + 16 * i + (lane & 15);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + 16 * j + 4 * (lane >> 4);
-            if (n >= p.N) continue;                       // N % 4 == 0 is enforced on the host
-            f32x4 v = acc[i][j] * p.alpha;
-            if (splitk) {
-                float* dst = p.c_f32 + (size_t)m * p.ldc_f32 + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
-                continue;
-            }
-            if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
-            if (p.act_grad_of) {
-                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
-            }
-            if (p.pre_bf16) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
-            }
-            if (p.act != ACT_NONE) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
-            }
-            if (p.drop_p > 0.f) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
-            }
-            if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
-            if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
-            if (p.c_bf16) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
-            }
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wave * PER_WAVE + i;
+        const int pos = inst * 64 + lane;       // 16-B chunk index in LDS order
+        const bf16_t* src;
+        if (KC) {
+            const int r = pos >> 2, c = (pos & 3) ^ kc1_key(r);
+            const int gr = min(row0 + r, R - 1), gk = k0 + c * 8;
+            src = gk < Kend ? g + (size_t)gr * ld + gk : reinterpret_cast<const bf16_t*>(g_zero_page);
+        } else {
+            constexpr int CPR = ROWS / 8;
+            const int krow = pos / CPR, c = (pos % CPR) ^ rc_key<ROWS>(krow);
+            const int gk = k0 + krow, gr = row0 + c * 8;
+            src = (gk < Kend && gr < R) ? g + (size_t)gk * ld + gr : reinterpret_cast<const bf16_t*>(g_zero_page);
         }
+        // one opaque per-lane address -> exactly ONE DMA instruction per (wave, i): the counted vmcnt waits rely on it
+        unsigned long long addr = reinterpret_cast<unsigned long long>(src);
+        asm volatile("" : "+v"(addr));
+        __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(lds_tile + inst * 1024), 16, 0, 0);
     }
+}
+
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8 load_frag1(const char* lds, int r0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (KC) {
+        return *reinterpret_cast<const bf16x8*>(lds + kc1_off(r0 + i, g));
+    } else {
+        const int q = i >> 2, pp = i & 3;
+        const int col = r0 + 4 * pp;
+        const int krow = 8 * g + q;
+        const int o0 = rc_off<ROWS>(krow, col >> 3) + ((col & 7) << 1);
+        const int o1 = rc_off<ROWS>(krow + 4, col >> 3) + ((col & 7) << 1);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        return u.v;
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int STAGES1, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NTHREADS) void gemm_v1_kernel(const GemmArgs p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_BYTES = BM * BK1 * 2, B_BYTES = BN * BK1 * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int GL = (BM * 4 / 64) / 4 + (BN * 4 / 64) / 4;            // DMA instructions per wave per tile
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES1 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK1 - 1) / BK1;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int t) {
+        char* st = smem + (t % STAGES1) * STAGE_BYTES;
+        issue_tile<BM, A_KC>(st, p.a, p.lda, m0, p.M, kbeg + t * BK1, kend, wave, lane);
+        issue_tile<BN, B_KC>(st + A_BYTES, p.b, p.ldb, n0, p.N, kbeg + t * BK1, kend, wave, lane);
+    };
+    const int pre = min(nk, STAGES1 - 1);
+    for (int t = 0; t < pre; ++t) issue(t);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = min(nk - 1 - kt, STAGES1 - 2);      // younger tiles that may stay in flight
+        if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>(); else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                        // tile kt landed for every wave; stage (kt-1)%4 is free
+        if (kt + STAGES1 - 1 < nk) issue(kt + STAGES1 - 1);
+        const char* la = smem + (kt % STAGES1) * STAGE_BYTES;
+        const char* lb = la + A_BYTES;
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, wm * WTM + 16 * i, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = load_frag1<BN, B_KC>(lb, wn * WTN + 16 * j, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
+bool g_force_dma = false;
+
+int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
+
+template <int BM, int BN, int ST>
+int launch_v1s(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    dim3 grid(tiles, 1, splits), block(NTHREADS);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, true, false>), grid, block, 0, st, p);
+    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, false, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, false, true>), grid, block, 0, st, p);
+    return (int)hipGetLastError();
+}
+template <int BM, int BN>
+int launch_v1(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
+    if (g_v1_stages == 2) return launch_v1s<BM, BN, 2>(p, a_kc, b_kc, splits, st);
+    if (g_v1_stages == 3) return launch_v1s<BM, BN, 3>(p, a_kc, b_kc, splits, st);
+    return launch_v1s<BM, BN, 4>(p, a_kc, b_kc, splits, st);
 }
 
 bool g_use_tr = true;
@@ -269,6 +423,7 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 }  // namespace
 
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
+extern "C" void vqa_set_gemm_pipeline(int v1) { g_use_v1 = v1 != 0; g_force_dma = v1 != 0; g_v1_stages = (v1 >= 2 && v1 <= 4) ? v1 : 2; }
 
 extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -299,15 +454,21 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
-    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N)
-    const long t128 = (long)ceil_div(d->M, 128) * ceil_div(d->N, 128);
+    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128
+    bool dma = g_use_v1;     // LDS-DMA pipeline (2 stages unless overridden) vs register-staged double buffer
     if (d->tile_hint > 0) cfg = d->tile_hint - 1;
     else if (d->M <= 32) cfg = 2;
     else if (d->N <= 32) cfg = 3;
-    else if (t128 >= 200) cfg = 0;
-    else cfg = 1;
-    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : 128;
-    const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : 32;
+    else {
+        // measured on MI355X (profiles/r01/gemm_tiles.log).  Every shape of the path is bound by the per-CU operand
+        // load path (L2/MALL -> LDS), not by MFMA issue: 64x64 register-staged tiles at 5 workgroups/CU move the most
+        // bytes per CU; 128-row LDS-DMA tiles (half the traffic per FLOP) win only when N is wide enough to give
+        // every CU a tile.
+        cfg = 1; dma = false;
+        if (d->a_kc && d->M >= 1024 && d->N >= 2304) { cfg = d->b_kc ? 0 : 4; dma = true; }
+    }
+    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : 64;
+    const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : 128;
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
 
     int splits = d->split_k;
@@ -327,10 +488,20 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         hipError_t e = hipMemset2DAsync(d->c_f32, (size_t)d->ldc_f32 * 4, 0, (size_t)d->N * 4, d->M, stream);
         if (e != hipSuccess) return (int)e;
     }
+    if ((dma || g_force_dma) && g_use_tr && cfg != 2 && cfg != 3) {
+        switch (cfg) {
+            case 0: return launch_v1<128, 128>(p, d->a_kc, d->b_kc, splits, stream);
+            case 1: return launch_v1<64, 64>(p, d->a_kc, d->b_kc, splits, stream);
+            case 4: return launch_v1<128, 64>(p, d->a_kc, d->b_kc, splits, stream);
+            default: return launch_v1<64, 128>(p, d->a_kc, d->b_kc, splits, stream);
+        }
+    }
     switch (cfg) {
         case 0: return launch_cfg<128, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
         case 1: return launch_cfg<64, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
         case 2: return launch_cfg<32, 128, 1, 4>(p, d->a_kc, d->b_kc, splits, stream);
-        default: return launch_cfg<128, 32, 4, 1>(p, d->a_kc, d->b_kc, splits, stream);
+        case 3: return launch_cfg<128, 32, 4, 1>(p, d->a_kc, d->b_kc, splits, stream);
+        case 4: return launch_cfg<128, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
+        default: return launch_cfg<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
     }
 }

@@ -148,14 +148,26 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
     }
 }
 
-// final reduce of the per-block partials: out[c] = sum_b ws[b][c]
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int cols, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// final reduce of the per-block partials: out[c] = sum_b ws[b][c].  One workgroup per 64 columns; 16 row-groups of
+// partial rows are summed in parallel (coalesced 256-B reads per wave) and combined through LDS.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int cols, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    __shared__ float red[2][16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblocks; ++k) { a += ws[(size_t)k * cols + c]; b += ws[(size_t)(nblocks + k) * cols + c]; }
-    if (dgamma) dgamma[c] = a;
-    if (dbeta) dbeta[c] = b;
+    if (c < cols) {
+        for (int k = rg; k < nblocks; k += 16) { a += ws[(size_t)k * cols + c]; b += ws[(size_t)(nblocks + k) * cols + c]; }
+    }
+    red[0][rg][lane] = a; red[1][rg][lane] = b;
+    __syncthreads();
+    if (rg < 2 && c < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[rg][k][lane];
+        float* out = rg == 0 ? dgamma : dbeta;
+        if (out) out[c] = v;
+    }
 }
 
 constexpr int BWD_BLOCKS = 256;
@@ -208,7 +220,7 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (wsp) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)s, ws, grid, cols, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 64)), dim3(1024), 0, (hipStream_t)s, ws, grid, cols, dgamma, dbeta);
         e = hipGetLastError();
     }
     return (int)e;

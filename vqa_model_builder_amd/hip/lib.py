@@ -39,6 +39,7 @@ SIGNATURES = {
     'vqa_abi_version': (i32, []),
     'vqa_gemm_bf16': (i32, [C.POINTER(VqaGemmDesc), vp]),
     'vqa_set_gemm_use_tr': (None, [i32]),
+    'vqa_set_gemm_pipeline': (None, [i32]),
     'vqa_cast_f32_bf16': (i32, [vp, vp, sz, vp]),
     'vqa_cast_multi': (i32, [vp, i32, u64, vp]),
     'vqa_cast_bf16_f32': (i32, [vp, vp, sz, vp]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'vqa_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, u32, vp]),
     'vqa_layernorm_bwd_ws_floats': (sz, [i32]),
     'vqa_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, u32, i32, vp]),
+    'vqa_set_attention_mfma': (None, [i32]),
     'vqa_attention_fwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
     'vqa_attention_bwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
     'vqa_roberta_embed_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
