@@ -55,6 +55,7 @@ typedef struct VqaGemmDesc {
 } VqaGemmDesc;
 int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream);
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
+void vqa_set_gemm_group_m(int g);          /* tile-row group of the L2-aware tile order (default 16; <= 1 = row-major) */
 void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */
 
 /* ---- elementwise / layout --------------------------------------------------------------------------------- */

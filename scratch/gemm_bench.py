@@ -14,16 +14,16 @@ def bench(fn, iters=30):
 shapes = [('NT', 2048, 2304, 768), ('NT', 2048, 768, 768), ('NT', 2048, 3072, 768), ('NT', 2048, 768, 3072), ('NT', 1600, 2304, 768),
           ('NN', 2048, 768, 2304), ('NN', 2048, 768, 3072), ('NN', 2048, 3072, 768),
           ('TN', 2304, 768, 2048), ('TN', 768, 768, 2048), ('TN', 3072, 768, 2048), ('TN', 768, 3072, 2048), ('TN', 768, 768, 1600)]
-CFG = [(0, 2), (2, 1), (3, 1), (4, 1), (2, 2), (3, 2), (2, 5), (3, 5)]
-print('%-4s %-18s %s' % ('lay', 'M,N,K', ' | '.join('p%d/h%d' % c for c in CFG)))
+CFG = [(0, 2, 8), (2, 1, 8), (3, 1, 8), (2, 5, 8), (3, 5, 8), (2, 6, 8), (2, 2, 8), (4, 2, 8)]
+print('%-4s %-18s %s' % ('lay', 'M,N,K', ' | '.join('p%d/h%d/g%d' % c for c in CFG)))
 for lay, M, N, Kd in shapes:
     a = torch.randn((M, Kd) if lay != 'TN' else (Kd, M), device=dev).to(torch.bfloat16)
     b = torch.randn((N, Kd) if lay == 'NT' else (Kd, N), device=dev).to(torch.bfloat16)
     out = torch.empty((M, N), device=dev)
     outb = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
     res = []
-    for pl, h in CFG:
-        L.vqa_set_gemm_pipeline(pl)
+    for pl, h, gm in CFG:
+        L.vqa_set_gemm_pipeline(pl); L.vqa_set_gemm_group_m(gm)
         if True:
             if lay == 'NT': f = lambda: K.gemm(a, b, M, N, Kd, Kd, Kd, True, True, out_bf16=outb, tile_hint=h)
             elif lay == 'NN': f = lambda: K.gemm(a, b, M, N, Kd, Kd, N, True, False, out_bf16=outb, tile_hint=h)
@@ -31,4 +31,4 @@ for lay, M, N, Kd in shapes:
             us = bench(f)
             res.append('%5.1f %4.0f' % (us, 2.0 * M * N * Kd / us / 1e6))
     print('%-4s %-18s %s' % (lay, f'{M},{N},{Kd}', ' | '.join(res)))
-L.vqa_set_gemm_pipeline(1)
+L.vqa_set_gemm_pipeline(0); L.vqa_set_gemm_group_m(16)

@@ -38,6 +38,7 @@ struct GemmArgs {
     float alpha;
     float drop_p; float drop_inv_keep; unsigned long long drop_seed; unsigned int drop_stream;
     int k_per_split;                        // multiple of BK
+    int group_m;                            // tile-row group of the L2-aware tile order (<= 1: plain row-major)
 };
 
 // ---- LDS addressing -------------------------------------------------------------------------------------------
@@ -130,6 +131,29 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int 
     }
 }
 
+// blockIdx -> output tile.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b gets the
+// tile id  chunk(b % 8) + b / 8  and every XCD (private 4-MiB L2) works on one contiguous range of tile ids.
+// (2) Inside that range tiles are walked in GROUPS of group_m tile-rows, tile-row fastest: the ~160 workgroups an XCD
+// holds at once then cover a group_m x ~10 patch of the output, i.e. they share group_m A-panels and ~10 B-panels that
+// fit the L2 together, instead of one A-panel and EVERY B-panel (which thrashes it and sends each tile to the MALL).
+template <int BM, int BN>
+__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int t = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
+    }
+    const int gm = p.group_m;
+    if (gm <= 1) { tm = t / tiles_n; tn = t % tiles_n; return; }
+    const int per_group = gm * tiles_n;
+    const int g = t / per_group, r = t % per_group;
+    const int rows = min(gm, tiles_m - g * gm);
+    tm = g * gm + r % rows;
+    tn = r / rows;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane) {
     // lane holds C[m][n..n+3], m = m_base + 16*i + (lane&15), n = n_base + 16*j + 4*(lane>>4)
@@ -193,14 +217,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware tile order: consecutive tiles of one M-row-panel share the A panel -> keep them on one XCD's L2
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_coords<BM, BN>(p, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -276,50 +294,77 @@ __device__ __forceinline__ int kc1_off(int row, int chunk) { return row * 64 + (
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
+// Per-lane DMA descriptor of one 1-KiB wave-instruction of an operand tile: everything that does not depend on the
+// k-step is computed ONCE (row clamp, swizzled chunk, zero-page redirection); the k loop only adds `step` to `ptr`.
+struct DmaLane {
+    unsigned long long ptr;      // source address of this lane's 16 B for the NEXT tile to issue
+    unsigned long long step;     // bytes per k-tile (0 for lanes parked on the zero page)
+    int kmax;                    // lane is inside K while tile_k0 < kmax (only consulted for the ragged last tile)
+};
+
 template <int ROWS, bool KC>
-__device__ __forceinline__ void issue_tile(char* lds_tile, const bf16_t* __restrict__ g, int ld, int row0, int R, int k0, int Kend,
-                                           int wave, int lane) {
-    constexpr int INSTR = ROWS * 4 / 64;        // 1-KiB wave-instructions per tile
-    constexpr int PER_WAVE = INSTR / 4;
+__device__ __forceinline__ void dma_init(DmaLane (&d)[ROWS * 4 / 64 / 4], const bf16_t* __restrict__ g, int ld, int row0, int R,
+                                         int kbeg, int kend, int wave, int lane) {
+    constexpr int PER_WAVE = ROWS * 4 / 64 / 4;
+    const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-        const int inst = wave * PER_WAVE + i;
-        const int pos = inst * 64 + lane;       // 16-B chunk index in LDS order
-        const bf16_t* src;
+        const int pos = (wave * PER_WAVE + i) * 64 + lane;       // 16-B chunk index in LDS order
         if (KC) {
             const int r = pos >> 2, c = (pos & 3) ^ kc1_key(r);
-            const int gr = min(row0 + r, R - 1), gk = k0 + c * 8;
-            src = gk < Kend ? g + (size_t)gr * ld + gk : reinterpret_cast<const bf16_t*>(g_zero_page);
+            const int gr = min(row0 + r, R - 1);
+            d[i].ptr = reinterpret_cast<unsigned long long>(g + (size_t)gr * ld + kbeg + c * 8);
+            d[i].step = BK1 * 2;
+            d[i].kmax = kend - c * 8;
         } else {
             constexpr int CPR = ROWS / 8;
             const int krow = pos / CPR, c = (pos % CPR) ^ rc_key<ROWS>(krow);
-            const int gk = k0 + krow, gr = row0 + c * 8;
-            src = (gk < Kend && gr < R) ? g + (size_t)gk * ld + gr : reinterpret_cast<const bf16_t*>(g_zero_page);
+            const int gr = row0 + c * 8;
+            if (gr < R) {
+                d[i].ptr = reinterpret_cast<unsigned long long>(g + (size_t)(kbeg + krow) * ld + gr);
+                d[i].step = (unsigned long long)BK1 * ld * 2;
+                d[i].kmax = kend - krow;
+            } else { d[i].ptr = zero; d[i].step = 0; d[i].kmax = 0x7fffffff; }
         }
-        // one opaque per-lane address -> exactly ONE DMA instruction per (wave, i): the counted vmcnt waits rely on it
-        unsigned long long addr = reinterpret_cast<unsigned long long>(src);
-        asm volatile("" : "+v"(addr));
-        __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(lds_tile + inst * 1024), 16, 0, 0);
     }
 }
 
-template <int ROWS, bool KC>
-__device__ __forceinline__ bf16x8 load_frag1(const char* lds, int r0, int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    if (KC) {
-        return *reinterpret_cast<const bf16x8*>(lds + kc1_off(r0 + i, g));
-    } else {
-        const int q = i >> 2, pp = i & 3;
-        const int col = r0 + 4 * pp;
-        const int krow = 8 * g + q;
-        const int o0 = rc_off<ROWS>(krow, col >> 3) + ((col & 7) << 1);
-        const int o1 = rc_off<ROWS>(krow + 4, col >> 3) + ((col & 7) << 1);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
-        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-        u.s.a = lo; u.s.b = hi;
-        return u.v;
+template <int N_, bool CHECKED>
+__device__ __forceinline__ void dma_issue(DmaLane (&d)[N_], char* lds_tile, int k0, int wave) {
+#pragma unroll
+    for (int i = 0; i < N_; ++i) {
+        unsigned long long addr = d[i].ptr;
+        if (CHECKED) addr = k0 < d[i].kmax ? addr : reinterpret_cast<unsigned long long>(g_zero_page);
+        asm volatile("" : "+v"(addr));          // one opaque address -> exactly ONE DMA instruction (counted vmcnt waits)
+        __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(lds_tile + (wave * N_ + i) * 1024), 16, 0, 0);
+        d[i].ptr += d[i].step;
     }
+}
+
+// per-lane LDS byte offsets of the fragments of a wave tile, computed once (stage base is added as an immediate)
+template <int ROWS, bool KC, int NT>
+__device__ __forceinline__ void frag_offsets(int (&o0)[NT], int (&o1)[NT], int r_base, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r0 = r_base + 16 * t;
+        if (KC) { o0[t] = kc1_off(r0 + i, g); o1[t] = 0; }
+        else {
+            const int q = i >> 2, pp = i & 3, col = r0 + 4 * pp, krow = 8 * g + q;
+            o0[t] = rc_off<ROWS>(krow, col >> 3) + ((col & 7) << 1);
+            o1[t] = rc_off<ROWS>(krow + 4, col >> 3) + ((col & 7) << 1);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 load_frag1(const char* lds, int o0, int o1) {
+    if (KC) return *reinterpret_cast<const bf16x8*>(lds + o0);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -328,25 +373,26 @@ template <int BM, int BN, int STAGES1, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(NTHREADS) void gemm_v1_kernel(const GemmArgs p) {
     constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BK1 * 2, B_BYTES = BN * BK1 * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int GL = (BM * 4 / 64) / 4 + (BN * 4 / 64) / 4;            // DMA instructions per wave per tile
+    constexpr int PA = BM * 4 / 64 / 4, PB = BN * 4 / 64 / 4, GL = PA + PB;        // DMA instructions per wave per tile
     __shared__ __attribute__((aligned(1024))) char smem[STAGES1 * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_coords<BM, BN>(p, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK1 - 1) / BK1;
+    const int nk_full = (kend - kbeg) / BK1;                 // tiles entirely inside K: no per-lane k check needed
+
+    DmaLane da[PA], db[PB];
+    dma_init<BM, A_KC>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
+    dma_init<BN, B_KC>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+    int ao0[TM], ao1[TM], bo0[TN], bo1[TN];
+    frag_offsets<BM, A_KC, TM>(ao0, ao1, wm * WTM, lane);
+    frag_offsets<BN, B_KC, TN>(bo0, bo1, wn * WTN, lane);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -354,38 +400,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v1_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int t) {
-        char* st = smem + (t % STAGES1) * STAGE_BYTES;
-        issue_tile<BM, A_KC>(st, p.a, p.lda, m0, p.M, kbeg + t * BK1, kend, wave, lane);
-        issue_tile<BN, B_KC>(st + A_BYTES, p.b, p.ldb, n0, p.N, kbeg + t * BK1, kend, wave, lane);
+    auto issue = [&](int t, int stage) {
+        char* st = smem + stage * STAGE_BYTES;
+        if (t < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
+        else { dma_issue<PA, true>(da, st, kbeg + t * BK1, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + t * BK1, wave); }
     };
-    const int pre = min(nk, STAGES1 - 1);
-    for (int t = 0; t < pre; ++t) issue(t);
+#pragma unroll
+    for (int t = 0; t < STAGES1 - 1; ++t)
+        if (t < nk) issue(t, t);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int rem = min(nk - 1 - kt, STAGES1 - 2);      // younger tiles that may stay in flight
-        if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>(); else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                        // tile kt landed for every wave; stage (kt-1)%4 is free
-        if (kt + STAGES1 - 1 < nk) issue(kt + STAGES1 - 1);
-        const char* la = smem + (kt % STAGES1) * STAGE_BYTES;
-        const char* lb = la + A_BYTES;
-        bf16x8 fa[TM], fb[TN];
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, wm * WTM + 16 * i, lane);
+        for (int s = 0; s < STAGES1; ++s) {                  // compile-time stage index: LDS addresses fold to immediates
+            const int kt = kt0 + s;
+            if (kt < nk) {
+                const int rem = min(nk - 1 - kt, STAGES1 - 2);   // younger tiles that may stay in flight
+                if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>(); else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; stage (s-1) is free again
+                if (kt + STAGES1 - 1 < nk) issue(kt + STAGES1 - 1, (s + STAGES1 - 1) % STAGES1);
+                const char* la = smem + s * STAGE_BYTES;
+                const char* lb = la + A_BYTES;
+                bf16x8 fa[TM], fb[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = load_frag1<BN, B_KC>(lb, wn * WTN + 16 * j, lane);
+                for (int i = 0; i < TM; ++i) fa[i] = load_frag1<A_KC>(la, ao0[i], ao1[i]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) fb[j] = load_frag1<B_KC>(lb, bo0[j], bo1[j]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
     }
     gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
-
+int g_group_m = 16;
 int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
 
 template <int BM, int BN, int ST>
@@ -399,9 +452,9 @@ int launch_v1s(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
     return (int)hipGetLastError();
 }
 template <int BM, int BN>
-int launch_v1(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
-    if (g_v1_stages == 2) return launch_v1s<BM, BN, 2>(p, a_kc, b_kc, splits, st);
-    if (g_v1_stages == 3) return launch_v1s<BM, BN, 3>(p, a_kc, b_kc, splits, st);
+int launch_v1(const GemmArgs& p, int a_kc, int b_kc, int splits, int stages, hipStream_t st) {
+    if (stages == 2) return launch_v1s<BM, BN, 2>(p, a_kc, b_kc, splits, st);
+    if (stages == 3) return launch_v1s<BM, BN, 3>(p, a_kc, b_kc, splits, st);
     return launch_v1s<BM, BN, 4>(p, a_kc, b_kc, splits, st);
 }
 
@@ -423,6 +476,7 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 }  // namespace
 
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
+extern "C" void vqa_set_gemm_group_m(int g) { g_group_m = g; }
 extern "C" void vqa_set_gemm_pipeline(int v1) { g_use_v1 = v1 != 0; g_force_dma = v1 != 0; g_v1_stages = (v1 >= 2 && v1 <= 4) ? v1 : 2; }
 
 extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
@@ -452,20 +506,25 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
     p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
+    p.group_m = g_group_m;
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
     int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128
-    bool dma = g_use_v1;     // LDS-DMA pipeline (2 stages unless overridden) vs register-staged double buffer
+    bool dma = g_use_v1;     // LDS-DMA pipeline vs register-staged double buffer
+    int stages = g_v1_stages;
     if (d->tile_hint > 0) cfg = d->tile_hint - 1;
     else if (d->M <= 32) cfg = 2;
     else if (d->N <= 32) cfg = 3;
     else {
-        // measured on MI355X (profiles/r01/gemm_tiles.log).  Every shape of the path is bound by the per-CU operand
-        // load path (L2/MALL -> LDS), not by MFMA issue: 64x64 register-staged tiles at 5 workgroups/CU move the most
-        // bytes per CU; 128-row LDS-DMA tiles (half the traffic per FLOP) win only when N is wide enough to give
-        // every CU a tile.
+        // Measured on MI355X (profiles/r01/gemm_tiles.log).  Every shape of the path is bound by the per-CU operand load
+        // path (L2/MALL -> LDS, ~45 GB/s/CU sustained), not by MFMA issue, so the choice trades bytes per FLOP (bigger
+        // tiles) against workgroups per CU (smaller tiles, shallower rings):
+        //   k-contiguous A and a wide N   -> 128x64 tiles, 2-stage LDS-DMA ring (half the A traffic, 4-5 WGs/CU)
+        //   k-contiguous operands, N=768  -> 64x64 LDS-DMA, 4-stage ring when K is long enough to fill it
+        //   transposed operands (dW, dX with N=768) -> 64x64 register-staged double buffer (ds_read_tr path)
         cfg = 1; dma = false;
-        if (d->a_kc && d->M >= 1024 && d->N >= 2304) { cfg = d->b_kc ? 0 : 4; dma = true; }
+        if (d->a_kc && d->M >= 512 && d->N >= 1536) { cfg = 4; dma = true; stages = 2; }
+        else if (d->a_kc && d->b_kc && d->M >= 512) { cfg = 1; dma = true; stages = d->K >= 2048 ? 4 : 2; }
     }
     const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : 64;
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : 128;
@@ -490,10 +549,10 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     }
     if ((dma || g_force_dma) && g_use_tr && cfg != 2 && cfg != 3) {
         switch (cfg) {
-            case 0: return launch_v1<128, 128>(p, d->a_kc, d->b_kc, splits, stream);
-            case 1: return launch_v1<64, 64>(p, d->a_kc, d->b_kc, splits, stream);
-            case 4: return launch_v1<128, 64>(p, d->a_kc, d->b_kc, splits, stream);
-            default: return launch_v1<64, 128>(p, d->a_kc, d->b_kc, splits, stream);
+            case 0: return launch_v1<128, 128>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            case 1: return launch_v1<64, 64>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            case 4: return launch_v1<128, 64>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            default: return launch_v1<64, 128>(p, d->a_kc, d->b_kc, splits, stages, stream);
         }
     }
     switch (cfg) {
