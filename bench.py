@@ -71,15 +71,38 @@ def synthetic_batch(B, device, rank):
     return px, ids, mask, labels
 
 
-def cpu_baseline(workload, steps=3, B=8):
+def usable_cores():
+    """Cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(workload, steps=6, B=32, budget_s=30.0):
     """The CPU oracle (plain fp32 torch on the host cores) running the same step definition on a bounded sample."""
     from oracle import det_weights as dw
     from oracle import vqa_oracle as vo
     from tests.conftest import CfgView, load_golden
     tag = {'cfg2_xattn': 'full_cfg2_xattn', 'cfg1_concat': 'full_cfg1_concat', 'cfg3_mcan_moe4': 'full_cfg3_mcan_moe4'}[workload]
     _, meta = load_golden(tag)
-    cores = os.cpu_count()
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    print(f'[bench] cpu_baseline: oracle on {cores} host threads, batch {B} ...', file=sys.stderr, flush=True)
     sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, 1)
     leaves = {k: v.requires_grad_(v.is_floating_point() and v.dim() > 0) for k, v in sd.items()}
     params = [v for v in leaves.values() if v.requires_grad]
@@ -87,7 +110,10 @@ def cpu_baseline(workload, steps=3, B=8):
     cfg = CfgView(meta)
     px, ids, mask, labels = dw.make_inputs(B, 64, 224, seed=3, pad_rows=False)
     times = []
+    t_start = time.perf_counter()
     for i in range(steps + 1):
+        if i >= 2 and time.perf_counter() - t_start > budget_s:
+            break
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         _, loss, _ = vo.vqa_forward(leaves, cfg, px, ids, mask, labels)
@@ -95,6 +121,8 @@ def cpu_baseline(workload, steps=3, B=8):
         torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
         opt.step()
         times.append(time.perf_counter() - t0)
+        print(f'[bench] cpu_baseline step {i}: {times[-1]:.2f} s', file=sys.stderr, flush=True)
+    steps = len(times) - 1
     t = sorted(times[1:])[len(times[1:]) // 2]
     model_name = ''
     try:
@@ -142,7 +170,7 @@ def main():
     model = build_model(args.workload, device).train()
     opt = make_optimizer(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    reducer = GradReducer(params) if world > 1 else None
+    reducer = GradReducer(params).attach() if world > 1 else None      # overlap: buckets go on the wire during backward
     px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
 
     def step():
@@ -150,7 +178,7 @@ def main():
         out = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
         out.loss.backward()
         if reducer is not None:
-            reducer.reduce()
+            reducer.finalize()
         torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
         opt.step()
         return out.loss

@@ -64,3 +64,32 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match='GPU'):
         model(pixel_values=torch.zeros(1, 3, d['image'], d['image']), input_ids=torch.zeros(1, d['seq'], dtype=torch.long),
               attention_mask=torch.ones(1, d['seq'], dtype=torch.long))
+
+
+def test_install_as_src_aliases_the_reference_import_paths():
+    import importlib
+    import sys
+    import vqa_model_builder_amd as amd
+    saved = {k: v for k, v in sys.modules.items() if k == 'src' or k.startswith('src.')}
+    try:
+        amd.install_as_src(force=True)
+        from src.modeling.meta_arch import VietnameseVQAModel, VQAModelConfig      # model_pipeline.py:189-197,307
+        from src.modeling.moe import VQAMOELayer                                     # vqa_model.py:529
+        from src.modeling.moe.router import create_router                            # ablation_trainer.py:205
+        assert VietnameseVQAModel.__module__.startswith('vqa_model_builder_amd')
+        assert VQAMOELayer.__module__.startswith('vqa_model_builder_amd') and callable(create_router)
+    finally:
+        for k in [k for k in sys.modules if k == 'src' or k.startswith('src.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_pipeline_config_surface():
+    from vqa_model_builder_amd.core import ModelPipelineConfig, TrainingPipelineConfig, VQAPipelineConfig, build_model_config
+    mc = ModelPipelineConfig(fusion_type='mcan', use_moe=True, moe_num_experts=4)
+    cfg = build_model_config(mc)
+    assert cfg.fusion.fusion_type == 'mcan' and cfg.fusion.output_dim == 768 and cfg.moe.use_moe and cfg.moe.hidden_dim == 2048
+    assert cfg.answer_head.hidden_dims == [768, 512] and cfg.text_encoder.max_length == 64
+    assert TrainingPipelineConfig().learning_rate == 2e-5 and VQAPipelineConfig().model.fusion_num_layers == 2
+    import dataclasses
+    assert len(dataclasses.fields(ModelPipelineConfig)) == 28

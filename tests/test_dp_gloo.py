@@ -1,0 +1,127 @@
+"""Data-parallel gradient exchange on CPU: world_size 2 over gloo (the N > 1 path of bench.py uses the same
+GradReducer over RCCL).  Checks: averaged gradients equal the mean of the per-rank gradients, parameters with a
+gradient on only ONE rank are zero-filled on the other (never skipped: no collective mismatch), parameters with no
+gradient on ANY rank keep grad None (the optimiser skips them, like the reference's single-process loop would),
+frozen parameters are not part of the exchange, and buckets respect the size cap."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from vqa_model_builder_amd.dp import GradReducer
+        torch.manual_seed(0)
+        shapes = [(7, 5), (33,), (64, 16), (3,), (10, 10), (1,)]
+        params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+        params[3].requires_grad_(False)                       # frozen: not exchanged
+        red = GradReducer(params, bucket_mb=0.004)            # ~1k floats per bucket -> several buckets
+        assert len(red.buckets) >= 2
+        assert all(b.numel * 4 <= 0.004 * 1024 * 1024 or len(b.params) == 1 for b in red.buckets)
+        g = torch.Generator().manual_seed(100 + rank)
+        local = {}
+        for i, p in enumerate(params):
+            if not p.requires_grad:
+                continue
+            if i == 4 and rank == 1:
+                continue                                       # only rank 0 has a gradient for param 4 (skipped expert)
+            if i == 5:
+                continue                                       # nobody has a gradient for param 5 (dead parameter)
+            p.grad = torch.randn(p.shape, generator=g)
+            local[i] = p.grad.numpy().copy()
+        red.reduce()
+        out = {i: (None if p.grad is None else p.grad.numpy().copy()) for i, p in enumerate(params)}
+        q.put((rank, local, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, local, out = q.get(timeout=120)
+        res[rank] = (local, out)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (l0, o0), (l1, o1) = res[0], res[1]
+    import numpy as np
+    for i in (0, 1, 2):
+        want = (l0[i] + l1[i]) / 2
+        assert np.allclose(o0[i], want, atol=1e-6) and np.allclose(o1[i], want, atol=1e-6)
+    assert np.allclose(o0[4], l0[4] / 2, atol=1e-6) and np.allclose(o1[4], l0[4] / 2, atol=1e-6)   # zero-filled on rank 1
+    assert o0[5] is None and o1[5] is None                    # no gradient anywhere -> stays None
+    assert o0[3] is None and o1[3] is None                    # frozen
+
+
+def test_single_process_is_a_noop():
+    from vqa_model_builder_amd.dp import GradReducer
+    p = torch.nn.Parameter(torch.ones(4))
+    p.grad = torch.full((4,), 2.0)
+    GradReducer([p]).reduce()
+    assert torch.equal(p.grad, torch.full((4,), 2.0))
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from vqa_model_builder_amd.dp import GradReducer
+        torch.manual_seed(0)                                  # identical replicas
+        model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                                    torch.nn.Linear(32, 4))
+        dead = torch.nn.Parameter(torch.ones(5))              # never used: no gradient on any rank
+        params = list(model.parameters()) + [dead]
+        red = GradReducer(params, bucket_mb=0.002).attach()
+        outs = []
+        for step in range(2):                                 # two steps: buckets re-arm
+            g = torch.Generator().manual_seed(10 * step + rank)
+            x = torch.randn(8, 16, generator=g)
+            for p in params:
+                p.grad = None
+            model(x).square().mean().backward()
+            local = [p.grad.numpy().copy() if p.grad is not None else None for p in params]
+            red.finalize()
+            outs.append((local, [p.grad.numpy().copy() if p.grad is not None else None for p in params]))
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlap_hooks_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(2):
+        (l0, o0), (l1, o1) = res[0][step], res[1][step]
+        for i in range(len(l0) - 1):
+            want = (l0[i] + l1[i]) / 2
+            import numpy as np
+            assert np.allclose(o0[i], want, atol=1e-6) and np.allclose(o1[i], want, atol=1e-6), (step, i)
+        assert o0[-1] is None and o1[-1] is None

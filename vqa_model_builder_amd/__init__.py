@@ -5,4 +5,45 @@ Public surface mirrors the reference's ``src.modeling.meta_arch`` / ``src.modeli
 training loop imports this implementation unchanged.
 """
 
+import importlib
+import sys
+import types
+
 __version__ = '0.1.0'
+
+_ALIASES = {
+    'src.modeling.meta_arch': 'vqa_model_builder_amd.modeling.meta_arch',
+    'src.modeling.meta_arch.vqa_config': 'vqa_model_builder_amd.modeling.meta_arch.vqa_config',
+    'src.modeling.meta_arch.vqa_model': 'vqa_model_builder_amd.modeling.meta_arch.vqa_model',
+    'src.modeling.moe': 'vqa_model_builder_amd.modeling.moe',
+    'src.modeling.moe.router': 'vqa_model_builder_amd.modeling.moe.router',
+    'src.modeling.moe.moe_layer': 'vqa_model_builder_amd.modeling.moe.moe_layer',
+    'src.modeling.moe.moe_config': 'vqa_model_builder_amd.modeling.moe.moe_config',
+    'src.modeling.moe.expert_types': 'vqa_model_builder_amd.modeling.moe.experts',
+    'src.modeling.moe.specialized_experts': 'vqa_model_builder_amd.modeling.moe.experts',
+    'src.modeling.moe.base_expert': 'vqa_model_builder_amd.modeling.moe.experts',
+}
+
+
+def install_as_src(force: bool = False):
+    """Registers this package's modules under the dotted names the reference imports them by
+    (``from src.modeling.meta_arch import ...`` model_pipeline.py:189-197,307; ``from src.modeling.moe import VQAMOELayer``
+    vqa_model.py:529; ``from src.modeling.moe.router import create_router`` ablation_trainer.py:205).  Parent packages
+    ``src`` / ``src.modeling`` are created as namespace stubs only when they are not importable already, so the rest of
+    the reference tree (``src.core``, ``src.data`` ...) keeps resolving to the reference's own files."""
+    for parent in ('src', 'src.modeling'):
+        if parent not in sys.modules:
+            try:
+                importlib.import_module(parent)
+            except Exception:
+                m = types.ModuleType(parent)
+                m.__path__ = []
+                sys.modules[parent] = m
+    for alias, target in _ALIASES.items():
+        if force or alias not in sys.modules or not getattr(sys.modules[alias], '__file__', '').startswith(__path__[0]):
+            mod = importlib.import_module(target)
+            sys.modules[alias] = mod
+            parent, _, leaf = alias.rpartition('.')
+            if parent in sys.modules:
+                setattr(sys.modules[parent], leaf, mod)
+    return sorted(_ALIASES)

@@ -1,0 +1,2 @@
+from .pipeline_config import (DataPipelineConfig, ModelPipelineConfig, TrainingPipelineConfig, VQAPipelineConfig,  # noqa: F401
+                              build_model_config)

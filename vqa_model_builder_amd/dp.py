@@ -11,7 +11,11 @@ The reference has no multi-device code at all: this is new work, sha
     no gradient on ANY rank keep ``grad = None`` so the optimiser skips them exactly like the reference's would
     (decided by a tiny all-reduced presence bitmap that rides in the first bucket);
   * xGMI is point-to-point (7 links/GPU): buckets are sized in tens of MB so RCCL's direct all-to-all-style
-    algorithms keep all links busy, and each bucket's all-reduce is launched asynchronously as soon as it is packed.
+    algorithms keep all links busy, and each bucket's all-reduce is launched asynchronously as soon as it is packed;
+  * overlap (``attach()``): a post-accumulate hook per parameter packs its gradient into the bucket the moment autograd
+    produces it and the bucket goes on the wire when its last expected gradient has arrived -- the answer head / MoE /
+    fusion buckets and the first encoder's buckets travel while the remaining backward still computes; ``finalize()``
+    after ``backward()`` sends whatever is left (zero-filling absent gradients), waits, averages and re-points ``.grad``.
 """
 
 from typing import List, Optional
@@ -21,10 +25,11 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ('params', 'offsets', 'numel', 'flat', 'work')
+    __slots__ = ('params', 'offsets', 'numel', 'flat', 'work', 'filled', 'pending')
 
     def __init__(self):
         self.params, self.offsets, self.numel, self.flat, self.work = [], [], 0, None, None
+        self.filled, self.pending = [], 0
 
 
 class GradReducer:
@@ -47,6 +52,83 @@ class GradReducer:
             self.buckets.append(cur)
         self.nparams = sum(len(b.params) for b in self.buckets)
         self._presence = None
+        self._where = {}
+        for bi, b in enumerate(self.buckets):
+            for si, p in enumerate(b.params):
+                self._where[id(p)] = (bi, si)
+        self._hooks = []
+        self._armed = False
+
+    # ---- overlap mode ---------------------------------------------------------------------------------------------
+    def attach(self):
+        """Registers the per-parameter hooks (idempotent).  Use ``finalize()`` instead of ``reduce()`` afterwards."""
+        if self._hooks or self.world == 1:
+            return self
+        for b in self.buckets:
+            for p in b.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        return self
+
+    def _arm(self, device):
+        self._ensure(device)
+        for b in self.buckets:
+            b.filled = [False] * len(b.params)
+            b.pending = len(b.params)
+            b.work = None
+        self._armed = True
+
+    @torch.no_grad()
+    def _on_grad(self, p):
+        if p.grad is None:
+            return
+        if not self._armed:
+            self._arm(p.grad.device)
+        bi, si = self._where[id(p)]
+        b = self.buckets[bi]
+        if b.filled[si] or b.work is not None:          # second accumulation in one step (grad accumulation): handled in finalize
+            return
+        off = b.offsets[si]
+        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        b.filled[si] = True
+        b.pending -= 1
+        if b.pending == 0:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def finalize(self):
+        """Call after ``loss.backward()`` in overlap mode."""
+        if self.world == 1:
+            return
+        device = self.buckets[0].params[0].device
+        if not self._armed:
+            self._arm(device)
+        flags = [0.0 if p.grad is None else 1.0 for b in self.buckets for p in b.params]
+        self._presence.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
+        pres_work = dist.all_reduce(self._presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:                       # buckets an absent gradient kept off the wire
+            if b.work is not None:
+                continue
+            for si, (p, off) in enumerate(zip(b.params, b.offsets)):
+                view = b.flat[off:off + p.numel()]
+                if p.grad is None:
+                    view.zero_()
+                elif not b.filled[si]:
+                    view.copy_(p.grad.reshape(-1))
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        pres_work.wait()
+        self._assign(self._presence.tolist())
+        self._armed = False
+
+    def _assign(self, present):
+        scale = 1.0 / self.world if self.average else 1.0
+        i = 0
+        for b in self.buckets:
+            b.work.wait()
+            if scale != 1.0:
+                b.flat.mul_(scale)
+            for p, off in zip(b.params, b.offsets):
+                p.grad = b.flat[off:off + p.numel()].view(p.shape) if present[i] > 0 else None
+                i += 1
 
     def _ensure(self, device):
         for b in self.buckets:
@@ -85,19 +167,7 @@ class GradReducer:
                 torch._foreach_copy_(dsts, srcs)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         pres_work.wait()
-        present = self._presence.tolist()
-        scale = 1.0 / self.world if self.average else 1.0
-        i = 0
-        for b in self.buckets:
-            b.work.wait()
-            if scale != 1.0:
-                b.flat.mul_(scale)
-            for p, off in zip(b.params, b.offsets):
-                if present[i] > 0:
-                    p.grad = b.flat[off:off + p.numel()].view(p.shape)
-                else:
-                    p.grad = None
-                i += 1
+        self._assign(self._presence.tolist())
 
     def bytes_per_step(self) -> int:
         return sum(b.numel for b in self.buckets) * 4
