@@ -53,13 +53,16 @@ def build_model(workload, device):
     return model
 
 
-def make_optimizer(model):
+def make_optimizer(model, use_torch=False):
     """Param groups of the reference loop (training_pipeline.py:239-252): no decay for bias / LayerNorm weights."""
     nd = ('bias', 'LayerNorm.weight', 'layer_norm.weight')
     decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(t in n for t in nd)]
     no_decay = [p for n, p in model.named_parameters() if p.requires_grad and any(t in n for t in nd)]
-    return torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': no_decay, 'weight_decay': 0.0}],
-                             lr=2e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
+    from vqa_model_builder_amd.optim import FusedAdamW
+    groups = [{'params': decay, 'weight_decay': 0.01}, {'params': no_decay, 'weight_decay': 0.0}]
+    if use_torch:
+        return torch.optim.AdamW(groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
+    return FusedAdamW(groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0).attach_shadows(model)
 
 
 def synthetic_batch(B, device, rank):
@@ -142,6 +145,7 @@ def main():
     ap.add_argument('--workload', default='cfg2_xattn', choices=list(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -168,7 +172,7 @@ def main():
     from vqa_model_builder_amd.dp import GradReducer
 
     model = build_model(args.workload, device).train()
-    opt = make_optimizer(model)
+    opt = make_optimizer(model, args.torch_optimizer)
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = GradReducer(params).attach() if world > 1 else None      # overlap: buckets go on the wire during backward
     px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
@@ -179,8 +183,9 @@ def main():
         out.loss.backward()
         if reducer is not None:
             reducer.finalize()
-        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
-        opt.step()
+        if args.torch_optimizer:
+            torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+        opt.step()                                   # FusedAdamW: global-norm clip (1.0) + AdamW + bf16 shadow refresh, fused
         return out.loss
 
     def fence():

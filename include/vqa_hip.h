@@ -51,7 +51,10 @@ typedef struct VqaGemmDesc {
     float drop_p; uint64_t drop_seed; uint32_t drop_stream;   /* inverted dropout on the output, index m*N+n */
     int split_k;                           /* 0 = auto (only if allow_split_k), 1 = off, >1 forced */
     int allow_split_k;                     /* fp32 atomics into c_f32 (zeroed here); plain fp32 output only */
-    int tile_hint;                         /* 0 auto; 1:128x128 2:64x64 3:32x128 4:128x32 */
+    int tile_hint;                         /* 0 auto; 1:128x128 2:64x64 3:32x128 4:128x32 5:128x64 6:64x128 */
+    float* colsum;                         /* optional fp32 [N], PRE-ZEROED by the caller: += column sums of the output values
+                                              (after bias/act'/dropout, before the residual): the bias gradient of the producer */
+    int c_prezeroed;                       /* split-K only: c_f32 is already zero, skip the memset */
 } VqaGemmDesc;
 int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream);
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
@@ -94,12 +97,14 @@ int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, cons
  * ws must hold vqa_layernorm_bwd_ws_floats(cols) floats.  dx_bf16 = optional bf16 copy of dx.
  * drop_mode 1: dx_bf16 is additionally masked by the dropout (drop_*) that forward applied to the tensor
  *              whose gradient it is (x = r + dropout(t): dx_bf16 is dt); dx_f32 stays unmasked (dr).
- * drop_mode 2: dy is masked on load (forward was y = dropout(LN(x)) with the same drop_* at index row*cols+c). */
+ * drop_mode 2: dy is masked on load (forward was y = dropout(LN(x)) with the same drop_* at index row*cols+c).
+ * dx_colsum (optional, [cols]): column sums of the (masked) gradient that dx_bf16 holds = the bias gradient of the
+ *              Linear whose output was added into x; fused here so no separate pass over dx is needed.  cols <= 3328. */
 size_t vqa_layernorm_bwd_ws_floats(int cols);
 int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                      const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* ws,
-                      int rows, int cols, float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode,
-                      vqa_stream_t s);
+                      const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum,
+                      float* ws, int rows, int cols, float drop_p, uint64_t drop_seed, uint32_t drop_stream,
+                      int drop_mode, vqa_stream_t s);
 
 /* ---- attention: softmax(Q K^T / sqrt(Dh) + key_padding) V per (batch, head) ------------------------------
  * Replaces HF CLIP/RoBERTa self-attention and nn.MultiheadAttention's core (vqa_model.py:300,304).
@@ -175,6 +180,22 @@ typedef struct VqaAdamWDesc {
     const float* grad_scale;                /* optional device scalar multiplied into grad (clip coefficient) */
 } VqaAdamWDesc;
 int vqa_adamw_step(const VqaAdamWDesc* d, vqa_stream_t s);
+/* multi-tensor form: one launch over a DEVICE table of per-tensor jobs (all tensors 16-byte aligned).
+ * vqa_sumsq_multi: norm2[0] += sum over all jobs of |grad|^2 (caller zeroes norm2).
+ * vqa_adamw_multi: grad *= min(1, max_norm / (sqrt(norm2[0]) + 1e-6)) when norm2 != NULL and max_norm > 0
+ *                  (torch.nn.utils.clip_grad_norm_, training_pipeline.py:497), then the AdamW update with the job's own
+ *                  weight_decay (param groups of training_pipeline.py:239-252); shadow != NULL: also writes the
+ *                  parameter's bf16 (shadow_kind 0) or packed-fp32 (shadow_kind 1) copy the GEMMs read. */
+typedef struct VqaOptJob {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq; void* shadow;
+    uint64_t n; float weight_decay; uint32_t shadow_kind;
+} VqaOptJob;
+/* chunks_dev: uint32 [nchunks][2] = {job index, first element}; every chunk covers vqa_opt_chunk_elems() elements of its
+ * tensor (the last one of a tensor fewer): one workgroup per chunk keeps the chip streaming whatever the tensor sizes. */
+int vqa_opt_chunk_elems(void);
+int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, float* norm2, vqa_stream_t s);
+int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
+                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, vqa_stream_t s);
 /* sum of squares of a fp32 buffer accumulated into out[0] (atomic; caller zeroes) */
 int vqa_sumsq_f32(const float* x, uint64_t n, float* out, vqa_stream_t s);
 

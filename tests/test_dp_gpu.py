@@ -52,7 +52,7 @@ def test_model_gradients_average_across_two_ranks():
         p.start()
     res = {}
     for _ in range(2):
-        rank, local, reduced = q.get(timeout=300)
+        rank, local, reduced = q.get(timeout=120)
         res[rank] = (local, reduced)
     for p in procs:
         p.join(timeout=120)

@@ -109,6 +109,23 @@ def test_gemm_epilogue(act):
     assert torch.allclose(dxf, ref, atol=3e-3, rtol=2e-3)
 
 
+def test_gemm_epilogue_column_sums():
+    # bias gradient fused into the dX GEMM: colsum of (dy W) * act'(pre) over ragged M (rows >= M must contribute zero)
+    for M in (200, 64, 33):
+        N, Kd = 256, 320
+        dy, w = rnd((M, N), 1).to(DEV).to(BF), rnd((N, Kd), 2, 0.05).to(DEV).to(BF)
+        pre = rnd((M, Kd), 3).to(DEV).to(BF)
+        cs = torch.zeros((Kd,), device=DEV)
+        dxf, _ = K.linear_dx(dy, w, M, N, Kd, want_f32=True, act_grad_of=pre, act_bwd=K.ACT_GELU, colsum=cs)
+        assert torch.allclose(cs, dxf.sum(0), atol=2e-3, rtol=1e-4), M
+    # split-K into a pre-zeroed output (gradient arena): no memset inside
+    M, N, Kd = 768, 768, 2048
+    a, b = ints((M, Kd), seed=1).to(DEV), ints((N, Kd), seed=2).to(DEV)
+    out = torch.zeros((M, N), device=DEV)
+    K.gemm(a.t().contiguous().to(BF), b.t().contiguous().to(BF), M, N, Kd, M, N, False, False, out_f32=out, allow_split_k=True, c_prezeroed=True)
+    assert torch.equal(out, a @ b.t())
+
+
 def test_gemm_dropout_statistics_and_determinism():
     M, N, Kd = 512, 512, 64
     x, w = torch.ones((M, Kd), device=DEV, dtype=BF), torch.ones((N, Kd), device=DEV, dtype=BF) / Kd
@@ -125,7 +142,7 @@ def test_gemm_dropout_statistics_and_determinism():
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize('cols', [64, 768, 2048, 4096, 40])
+@pytest.mark.parametrize('cols', [64, 768, 2048, 3072, 40])
 def test_layernorm_fwd_bwd(cols):
     rows = 333
     x, add = rnd((rows, cols), 1).to(DEV), rnd((rows, cols), 2).to(DEV)
@@ -138,7 +155,9 @@ def test_layernorm_fwd_bwd(cols):
     assert torch.allclose(yb.float(), ref, atol=2e-2, rtol=1e-2)
     dy, dres = rnd((rows, cols), 5).to(DEV), rnd((rows, cols), 6).to(DEV)
     ref.backward(dy)
-    dx, dxb, dg, db = K.layernorm_bwd(dy, x + add, mean, rstd, g, rows, cols, dres=dres, want_bf16=True)
+    cs = torch.empty((cols,), device=DEV)
+    dx, dxb, dg, db = K.layernorm_bwd(dy, x + add, mean, rstd, g, rows, cols, dres=dres, want_bf16=True, dx_colsum=cs)
+    assert torch.allclose(cs, (xs.grad + dres).sum(0), atol=2e-3, rtol=1e-4)          # fused bias-gradient column sums
     assert torch.allclose(dx, xs.grad + dres, atol=5e-5, rtol=1e-4)
     assert torch.allclose(dxb.float(), xs.grad + dres, atol=5e-2, rtol=2e-2)
     assert torch.allclose(dg, gg.grad, atol=2e-3, rtol=1e-4)
@@ -348,3 +367,31 @@ def test_casts_and_colsum():
     jobs = torch.tensor([[a.data_ptr(), da.data_ptr(), 333, 0], [b.data_ptr(), db.data_ptr(), 1001, 1]], dtype=torch.int64, device=DEV)
     K.cast_multi(jobs, 2, 1001)
     assert torch.equal(da, a.to(BF)) and torch.equal(db, b)
+
+
+def test_fused_adamw_matches_torch():
+    """FusedAdamW (multi-tensor kernels, clip fused) == clip_grad_norm_ + torch.optim.AdamW over several steps, two
+    param groups (decay / no decay), odd sizes, a parameter without gradient; bf16 shadow written by the kernel."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    shapes = [(37, 19), (128,), (64, 64), (5,), (1000, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    mk = lambda ps, cls, **kw: cls([{'params': [ps[0], ps[2], ps[4]], 'weight_decay': 0.01}, {'params': [ps[1], ps[3]], 'weight_decay': 0.0}],
+                                   lr=1e-2, betas=(0.9, 0.999), eps=1e-8, **kw)
+    o_ref, o_mine = mk(ref, torch.optim.AdamW), mk(mine, FusedAdamW, max_grad_norm=1.0)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref, mine)):
+            if i == 3 and step % 2 == 0:
+                a.grad = b.grad = None
+                continue
+            g = torch.randn(a.shape, device=DEV) * (3.0 if step < 2 else 0.01)       # clipped in steps 0-1, not after
+            a.grad, b.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], 1.0)
+        o_ref.step()
+        o_mine.step()
+    for a, b in zip(ref, mine):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+    for a, b in zip(ref, mine):
+        if o_ref.state[a]:
+            assert torch.allclose(o_ref.state[a]['exp_avg_sq'], o_mine.state[b]['exp_avg_sq'], atol=1e-8, rtol=1e-5)

@@ -217,11 +217,93 @@ __global__ void adamw_kernel(const VqaAdamWDesc d) {
     }
 }
 
+// ---- multi-tensor optimiser: one launch over a device table of per-tensor jobs, split into 64K-element chunks -------
+// chunks[c] = {job index, first element}: one workgroup per chunk, so a 49 M-element embedding table and a 768-element
+// bias both keep the whole chip streaming (a per-tensor grid would leave the big tensors to a handful of workgroups).
+constexpr uint32_t OPT_CHUNK = 65536;
+
+__global__ void sumsq_multi_kernel(const VqaOptJob* __restrict__ jobs, const uint32_t* __restrict__ chunks, float* __restrict__ norm2) {
+    __shared__ float red[4];
+    const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
+    const uint64_t beg = chunks[2 * blockIdx.x + 1];
+    const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
+    const float* g = j.grad;
+    float acc = 0.f;
+    const uint64_t e4 = beg + (end - beg) / 4 * 4;
+    for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (uint64_t i = e4 + threadIdx.x; i < end; i += blockDim.x) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(norm2, t); }
+}
+
+// AdamW over every chunk; clip coefficient min(1, max_norm / (sqrt(norm2) + 1e-6)) computed on device
+// (torch.nn.utils.clip_grad_norm_ semantics); optionally refreshes the bf16 (or packed fp32) shadow of the parameter.
+__global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uint32_t* __restrict__ chunks, const float* __restrict__ norm2,
+                                   float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+    const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
+    const uint64_t beg = chunks[2 * blockIdx.x + 1];
+    const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
+    float gs = 1.f;
+    if (norm2 && max_norm > 0.f) { const float c = max_norm / (sqrtf(norm2[0]) + 1e-6f); gs = c < 1.f ? c : 1.f; }
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * j.weight_decay;
+    const uint64_t e4 = beg + (end - beg) / 4 * 4;
+    for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
+        f32x4 p = *reinterpret_cast<f32x4*>(j.param + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(j.grad + i) * gs;
+        f32x4 m = *reinterpret_cast<f32x4*>(j.exp_avg + i);
+        f32x4 v = *reinterpret_cast<f32x4*>(j.exp_avg_sq + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p[k] *= decay;
+            m[k] = beta1 * m[k] + (1.f - beta1) * g[k];
+            v[k] = beta2 * v[k] + (1.f - beta2) * g[k] * g[k];
+            p[k] -= step_size * (m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps));
+        }
+        *reinterpret_cast<f32x4*>(j.param + i) = p;
+        *reinterpret_cast<f32x4*>(j.exp_avg + i) = m;
+        *reinterpret_cast<f32x4*>(j.exp_avg_sq + i) = v;
+        if (j.shadow) {
+            if (j.shadow_kind == 0) { bf16x4 o; for (int k = 0; k < 4; ++k) o[k] = (bf16_t)p[k]; *reinterpret_cast<bf16x4*>((bf16_t*)j.shadow + i) = o; }
+            else *reinterpret_cast<f32x4*>((float*)j.shadow + i) = p;
+        }
+    }
+    for (uint64_t i = e4 + threadIdx.x; i < end; i += blockDim.x) {
+        float p = j.param[i] * decay;
+        const float g = j.grad[i] * gs;
+        const float m = beta1 * j.exp_avg[i] + (1.f - beta1) * g;
+        const float v = beta2 * j.exp_avg_sq[i] + (1.f - beta2) * g * g;
+        p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+        j.param[i] = p; j.exp_avg[i] = m; j.exp_avg_sq[i] = v;
+        if (j.shadow) { if (j.shadow_kind == 0) ((bf16_t*)j.shadow)[i] = (bf16_t)p; else ((float*)j.shadow)[i] = p; }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 int vqa_abi_version(void) { return 1; }
+
+int vqa_opt_chunk_elems(void) { return (int)OPT_CHUNK; }
+
+int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, float* norm2, vqa_stream_t s) {
+    if (!jobs_dev || !chunks_dev || nchunks <= 0 || !norm2) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(nchunks), dim3(TPB), 0, (hipStream_t)s, jobs_dev, chunks_dev, norm2);
+    return (int)hipGetLastError();
+}
+
+int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
+                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, vqa_stream_t s) {
+    if (!jobs_dev || !chunks_dev || nchunks <= 0) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(TPB), 0, (hipStream_t)s, jobs_dev, chunks_dev, norm2, max_norm, lr, beta1, beta2,
+                       eps, bias_correction1, bias_correction2);
+    return (int)hipGetLastError();
+}
 
 int vqa_cast_f32_bf16(const float* src, void* dst, size_t n, vqa_stream_t s) {
     if (!src || !dst) return VQA_ERR_ARG;

@@ -39,6 +39,7 @@ struct GemmArgs {
     float drop_p; float drop_inv_keep; unsigned long long drop_seed; unsigned int drop_stream;
     int k_per_split;                        // multiple of BK
     int group_m;                            // tile-row group of the L2-aware tile order (<= 1: plain row-major)
+    float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
 };
 
 // ---- LDS addressing -------------------------------------------------------------------------------------------
@@ -161,39 +162,61 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m_base + 16 * i + (lane & 15);
-        if (m >= p.M) continue;
+        const bool mok = m < p.M;
+        if (!mok && !p.colsum) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n_base + 16 * j + 4 * (lane >> 4);
-            if (n >= p.N) continue;                       // N % 4 == 0 is enforced on the host
+            if (n >= p.N) continue;                       // N % 4 == 0 is enforced on the host; uniform per 16-lane group
             f32x4 v = acc[i][j] * p.alpha;
             if (splitk) {
-                float* dst = p.c_f32 + (size_t)m * p.ldc_f32 + n;
+                if (mok) {
+                    float* dst = p.c_f32 + (size_t)m * p.ldc_f32 + n;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                }
                 continue;
             }
-            if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
-            if (p.act_grad_of) {
-                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+            if (mok) {
+                if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
+                if (p.act_grad_of) {
+                    const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
-            }
-            if (p.pre_bf16) {
-                bf16x4 o;
+                    for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
+                }
+                if (p.pre_bf16) {
+                    bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
-            }
-            if (p.act != ACT_NONE) {
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+                }
+                if (p.act != ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
-            }
-            if (p.drop_p > 0.f) {
+                    for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+                }
+                if (p.drop_p > 0.f) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
+                    for (int r = 0; r < 4; ++r)
+                        v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
+                }
+            } else {
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if (p.colsum) {
+                // every lane of the 16-lane group (rows m_base+16i+0..15, same 4 columns) takes part: sum over the rows by
+                // xor-shuffles inside the group, then ONE lane adds the 4 column sums (rows >= M contribute zeros)
+                f32x4 cs = v;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cs[r] += __shfl_xor(cs[r], o, 64);
+                }
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, cs[r]);
+                }
+            }
+            if (!mok) continue;
             if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
             if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
             if (p.c_bf16) {
@@ -507,6 +530,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
     p.group_m = g_group_m;
+    p.colsum = d->colsum;
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
     int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128
@@ -532,7 +556,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
 
     int splits = d->split_k;
     const bool can_split = d->c_f32 && !d->c_bf16 && !d->pre_bf16 && !d->bias && !d->residual && !d->act_grad_of &&
-                           d->act == ACT_NONE && d->drop_p == 0.f;
+                           d->act == ACT_NONE && d->drop_p == 0.f && !d->colsum;
     if (splits <= 0) {
         splits = 1;
         if (can_split && d->allow_split_k) {
@@ -543,7 +567,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     int kps = ceil_div(ceil_div(d->K, splits), BK) * BK;
     splits = ceil_div(d->K, kps);
     p.k_per_split = kps;
-    if (splits > 1) {
+    if (splits > 1 && !d->c_prezeroed) {
         hipError_t e = hipMemset2DAsync(d->c_f32, (size_t)d->ldc_f32 * 4, 0, (size_t)d->N * 4, d->M, stream);
         if (e != hipSuccess) return (int)e;
     }

@@ -70,14 +70,14 @@ template <int NV>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx, bf16_t* __restrict__ dxb,
-    float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [WAVES][2][cols]
+    float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode, int want_colsum) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [WAVES][3][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = cols / 4;
-    f32x4 dg[NV], db[NV], g[NV];
+    f32x4 dg[NV], db[NV], g[NV], cs[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; g[i] = dg[i];
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; g[i] = dg[i]; cs[i] = dg[i];
         const int c = lane + 64 * i;
         if (c < c4) g[i] = reinterpret_cast<const f32x4*>(gamma)[c];
     }
@@ -118,15 +118,16 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
                 for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[i][j] - s1 - xh[i][j] * s2);
                 if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * cols)[c];
                 if (dx) reinterpret_cast<f32x4*>(dx + (size_t)row * cols)[c] = o;
-                if (dxb) {
+                if (dxb || want_colsum) {
                     bf16x4 ob;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = o[j];
                         if (drop_mode == 1) t *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
                         ob[j] = (bf16_t)t;
+                        cs[i][j] += t;                 // column sum of the (masked) gradient = bias gradient of the producer Linear
                     }
-                    reinterpret_cast<bf16x4*>(dxb + (size_t)row * cols)[c] = ob;
+                    if (dxb) reinterpret_cast<bf16x4*>(dxb + (size_t)row * cols)[c] = ob;
                 }
             }
         }
@@ -136,36 +137,40 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
-        if (c < c4) { l4[(wave * 2 + 0) * c4 + c] = dg[i]; l4[(wave * 2 + 1) * c4 + c] = db[i]; }
+        if (c < c4) { l4[(wave * 3 + 0) * c4 + c] = dg[i]; l4[(wave * 3 + 1) * c4 + c] = db[i]; l4[(wave * 3 + 2) * c4 + c] = cs[i]; }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < c4; c += WAVES * 64) {
-        f32x4 a = l4[c], b = l4[c4 + c];
+        f32x4 a = l4[c], b = l4[c4 + c], d = l4[2 * c4 + c];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) { a += l4[(w * 2 + 0) * c4 + c]; b += l4[(w * 2 + 1) * c4 + c]; }
+        for (int w = 1; w < WAVES; ++w) { a += l4[(w * 3 + 0) * c4 + c]; b += l4[(w * 3 + 1) * c4 + c]; d += l4[(w * 3 + 2) * c4 + c]; }
         reinterpret_cast<f32x4*>(ws + (size_t)blockIdx.x * cols)[c] = a;
         reinterpret_cast<f32x4*>(ws + (size_t)(gridDim.x + blockIdx.x) * cols)[c] = b;
+        if (want_colsum) reinterpret_cast<f32x4*>(ws + (size_t)(2 * gridDim.x + blockIdx.x) * cols)[c] = d;
     }
 }
 
 // final reduce of the per-block partials: out[c] = sum_b ws[b][c].  One workgroup per 64 columns; 16 row-groups of
 // partial rows are summed in parallel (coalesced 256-B reads per wave) and combined through LDS.
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int cols, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta) {
-    __shared__ float red[2][16][64];
+                                                             float* __restrict__ dbeta, float* __restrict__ colsum) {
+    __shared__ float red[3][16][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, d = 0.f;
     if (c < cols) {
-        for (int k = rg; k < nblocks; k += 16) { a += ws[(size_t)k * cols + c]; b += ws[(size_t)(nblocks + k) * cols + c]; }
+        for (int k = rg; k < nblocks; k += 16) {
+            a += ws[(size_t)k * cols + c]; b += ws[(size_t)(nblocks + k) * cols + c];
+            if (colsum) d += ws[(size_t)(2 * nblocks + k) * cols + c];
+        }
     }
-    red[0][rg][lane] = a; red[1][rg][lane] = b;
+    red[0][rg][lane] = a; red[1][rg][lane] = b; red[2][rg][lane] = d;
     __syncthreads();
-    if (rg < 2 && c < cols) {
+    if (rg < 3 && c < cols) {
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[rg][k][lane];
-        float* out = rg == 0 ? dgamma : dbeta;
+        float* out = rg == 0 ? dgamma : rg == 1 ? dbeta : colsum;
         if (out) out[c] = v;
     }
 }
@@ -194,23 +199,28 @@ int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, cons
     return (int)hipGetLastError();
 }
 
-size_t vqa_layernorm_bwd_ws_floats(int cols) { return (size_t)2 * BWD_BLOCKS * cols; }
+size_t vqa_layernorm_bwd_ws_floats(int cols) { return (size_t)3 * BWD_BLOCKS * cols; }
 
 int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
-                      float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int cols, float drop_p,
-                      uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s) {
+                      float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int cols,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s) {
     if (drop_p <= 0.f) drop_mode = 0;
     if (!dy || !x || !mean || !rstd || !gamma || rows <= 0 || cols <= 0 || cols % 4 || cols > 4096) return VQA_ERR_ARG;
-    if ((dgamma || dbeta) && !ws) return VQA_ERR_ARG;
+    if ((dgamma || dbeta || dx_colsum) && !ws) return VQA_ERR_ARG;
     const int grid = min(ceil_div(rows, WAVES), BWD_BLOCKS);
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    float* wsp = (dgamma || dbeta) ? ws : nullptr;
-    const size_t lds_bytes = wsp ? (size_t)WAVES * 2 * cols * 4 : 0;
+    float* wsp = (dgamma || dbeta || dx_colsum) ? ws : nullptr;
+    const size_t lds_bytes = wsp ? (size_t)WAVES * 3 * cols * 4 : 0;
+    if (lds_bytes > 160 * 1024 - 256) return VQA_ERR_ARG;            // affine/colsum partials need 48*cols bytes of LDS: cols <= 3328
     const int nv = nv_for(cols);
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(WAVES * 64), lds_bytes, (hipStream_t)s, dy, x, mean, rstd, \
-                                      gamma, dres, dx_f32, (bf16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode)
+                                      gamma, dres, dx_f32, (bf16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode, dx_colsum ? 1 : 0)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
-    else if (nv <= 8) LN_BWD(8); else {
+    else if (nv <= 8) {
+        static bool attr8 = false;       // 8 float4/lane: 96 KiB of LDS for the three-way cross-wave combine
+        if (!attr8) { (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr8 = true; }
+        LN_BWD(8);
+    } else {
         // 16 float4/lane: 128 KiB of LDS for the cross-wave combine exceeds the default dynamic limit
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_set = true; }
@@ -220,7 +230,7 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (wsp) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 64)), dim3(1024), 0, (hipStream_t)s, ws, grid, cols, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 64)), dim3(1024), 0, (hipStream_t)s, ws, grid, cols, dgamma, dbeta, dx_colsum);
         e = hipGetLastError();
     }
     return (int)e;

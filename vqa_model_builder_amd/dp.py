@@ -58,6 +58,7 @@ class GradReducer:
                 self._where[id(p)] = (bi, si)
         self._hooks = []
         self._armed = False
+        self._next = 0
 
     # ---- overlap mode ---------------------------------------------------------------------------------------------
     def attach(self):
@@ -75,6 +76,7 @@ class GradReducer:
             b.filled = [False] * len(b.params)
             b.pending = len(b.params)
             b.work = None
+        self._next = 0
         self._armed = True
 
     @torch.no_grad()
@@ -85,14 +87,22 @@ class GradReducer:
             self._arm(p.grad.device)
         bi, si = self._where[id(p)]
         b = self.buckets[bi]
-        if b.filled[si] or b.work is not None:          # second accumulation in one step (grad accumulation): handled in finalize
+        if b.filled[si] or bi < self._next:             # second accumulation in one step (grad accumulation): handled in finalize
             return
         off = b.offsets[si]
         b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
         b.filled[si] = True
         b.pending -= 1
-        if b.pending == 0:
+        self._launch_ready()
+
+    def _launch_ready(self):
+        # Collectives are matched across ranks BY ORDER, and which gradients exist is data dependent (an expert no token
+        # was routed to on this rank): buckets therefore go on the wire strictly in index order -- a bucket waits for its
+        # own gradients AND for every earlier bucket; whatever is still held back is sent, in the same order, by finalize().
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            b = self.buckets[self._next]
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._next += 1
 
     @torch.no_grad()
     def finalize(self):
@@ -103,11 +113,7 @@ class GradReducer:
         if not self._armed:
             self._arm(device)
         flags = [0.0 if p.grad is None else 1.0 for b in self.buckets for p in b.params]
-        self._presence.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
-        pres_work = dist.all_reduce(self._presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for b in self.buckets:                       # buckets an absent gradient kept off the wire
-            if b.work is not None:
-                continue
+        for b in self.buckets[self._next:]:          # buckets an absent gradient (here or earlier) kept off the wire, in order
             for si, (p, off) in enumerate(zip(b.params, b.offsets)):
                 view = b.flat[off:off + p.numel()]
                 if p.grad is None:
@@ -115,6 +121,9 @@ class GradReducer:
                 elif not b.filled[si]:
                     view.copy_(p.grad.reshape(-1))
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._next = len(self.buckets)
+        self._presence.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
+        pres_work = dist.all_reduce(self._presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # always LAST in the sequence
         pres_work.wait()
         self._assign(self._presence.tolist())
         self._armed = False

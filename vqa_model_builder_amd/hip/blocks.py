@@ -22,6 +22,27 @@ def new_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
 
 
+class GradArena:
+    """One flat, zero-filled fp32 buffer per block and backward pass holding every parameter gradient of the block
+    (packed where the weights are packed).  One fill kernel replaces the per-GEMM split-K memsets and lets the GEMM /
+    LayerNorm epilogues accumulate bias gradients in place; the block's gradients are contiguous for the DP exchange."""
+
+    def __init__(self, params):
+        self.slots, self.total = {}, 0
+        for key, p in params.items():
+            ps = p if isinstance(p, (list, tuple)) else [p]
+            shape = (sum(q.shape[0] for q in ps),) + tuple(ps[0].shape[1:])
+            n = 1
+            for d in shape:
+                n *= d
+            self.slots[key] = (self.total, n, shape)
+            self.total += (n + 3) // 4 * 4                      # 16-byte aligned slots
+
+    def alloc(self, device):
+        flat = torch.zeros(self.total, dtype=F32, device=device)
+        return flat, {k: flat[o:o + n].view(shape) for k, (o, n, shape) in self.slots.items()}
+
+
 def _mask_u8(mask_bool):
     if mask_bool is None:
         return None
@@ -37,6 +58,7 @@ class ClipRunner:
 
     def __init__(self, W, num_layers, D, heads, inter, patch, eps=1e-5):
         self.W, self.L, self.D, self.H, self.I, self.ps, self.eps = W, num_layers, D, heads, inter, patch, eps
+        self.arena = GradArena(W.params)
 
     def forward(self, px):
         W, D, H, I = self.W, self.D, self.H, self.I
@@ -65,35 +87,35 @@ class ClipRunner:
         W, D, H, I = self.W, self.D, self.H, self.I
         B, P = saved['B'], saved['P']
         T, M = P + 1, B * (P + 1)
-        G = {}
         dx = dout.reshape(M, D).contiguous().float()
+        _, G = self.arena.alloc(dx.device)
         dxb = K.cast_bf16(dx)
+        K.colsum_bf16(dxb, M, D, out=G[f'l{self.L - 1}.fc2_b'])          # later layers get it fused into LN1-backward
         for l in reversed(range(self.L)):
             k = f'l{l}.'
             x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g = saved['layers'][l]
-            _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU)
-            G[k + 'fc2_w'] = K.linear_dw(dxb, g, M, D, I)
-            G[k + 'fc2_b'] = K.colsum_bf16(dxb, M, D)
+            _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU, colsum=G[k + 'fc1_b'])
+            K.linear_dw(dxb, g, M, D, I, out=G[k + 'fc2_w'], prezeroed=True)
             dh2, _ = K.linear_dx(da, W.s(k + 'fc1_w'), M, I, D, want_f32=True)
-            G[k + 'fc1_w'] = K.linear_dw(da, h2, M, I, D)
-            G[k + 'fc1_b'] = K.colsum_bf16(da, M, I)
-            dx1, dx1b, G[k + 'ln2.w'], G[k + 'ln2.b'] = K.layernorm_bwd(dh2, x1, m2, r2, W.p(k + 'ln2.w'), M, D, dres=dx, want_bf16=True)
+            K.linear_dw(da, h2, M, I, D, out=G[k + 'fc1_w'], prezeroed=True)
+            dx1, dx1b, _, _ = K.layernorm_bwd(dh2, x1, m2, r2, W.p(k + 'ln2.w'), M, D, dres=dx, want_bf16=True,
+                                              dgamma=G[k + 'ln2.w'], dbeta=G[k + 'ln2.b'], dx_colsum=G[k + 'out_b'])
             _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
-            G[k + 'out_w'] = K.linear_dw(dx1b, ctx, M, D, D)
-            G[k + 'out_b'] = K.colsum_bf16(dx1b, M, D)
+            K.linear_dw(dx1b, ctx, M, D, D, out=G[k + 'out_w'], prezeroed=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dx.device)
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, T, T, D // H,
                             dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D)
             dh1, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True)
-            G[k + 'qkv_w'] = K.linear_dw(dqkv, h1, M, 3 * D, D)
-            G[k + 'qkv_b'] = K.colsum_bf16(dqkv, M, 3 * D)
-            dx, dxb, G[k + 'ln1.w'], G[k + 'ln1.b'] = K.layernorm_bwd(dh1, x, m1, r1, W.p(k + 'ln1.w'), M, D, dres=dx1, want_bf16=True)
-        du, _, G['pre_ln.w'], G['pre_ln.b'] = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('pre_ln.w'), M, D)
-        G['cls'] = torch.empty((D,), dtype=F32, device=dx.device)
-        G['pos'] = torch.empty((T, D), dtype=F32, device=dx.device)
+            K.linear_dw(dqkv, h1, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=True)
+            K.colsum_bf16(dqkv, M, 3 * D, out=G[k + 'qkv_b'])
+            nxt = G[f'l{l - 1}.fc2_b'] if l > 0 else None                  # dx is the fc2 output gradient of the layer below
+            dx, dxb, _, _ = K.layernorm_bwd(dh1, x, m1, r1, W.p(k + 'ln1.w'), M, D, dres=dx1, want_bf16=True,
+                                            dgamma=G[k + 'ln1.w'], dbeta=G[k + 'ln1.b'], dx_colsum=nxt)
+        du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('pre_ln.w'), M, D,
+                                      dgamma=G['pre_ln.w'], dbeta=G['pre_ln.b'])
         dE = K.clip_assemble_bwd(du, B, P, D, G['cls'], G['pos'])
         Kp = saved['xp'].shape[1]
-        G['patch_w'] = K.linear_dw(dE, saved['xp'], B * P, D, Kp)
+        K.linear_dw(dE, saved['xp'], B * P, D, Kp, out=G['patch_w'].view(D, Kp), prezeroed=True)
         return G
 
 
@@ -105,6 +127,7 @@ class RobertaRunner:
     def __init__(self, W, num_layers, D, heads, inter, pad_id=1, hidden_drop=0.1, attn_drop=0.1, eps=1e-5):
         self.W, self.L, self.D, self.H, self.I = W, num_layers, D, heads, inter
         self.pad, self.pd, self.pa, self.eps = pad_id, hidden_drop, attn_drop, eps
+        self.arena = GradArena(W.params)
 
     def forward(self, ids, attention_mask, training):
         W, D, H, I = self.W, self.D, self.H, self.I
@@ -137,39 +160,33 @@ class RobertaRunner:
         W, D, H, I = self.W, self.D, self.H, self.I
         B, S, seed, pd, pa, kpm = saved['B'], saved['S'], saved['seed'], saved['pd'], saved['pa'], saved['kpm']
         M = B * S
-        G = {}
         dx = dout.reshape(M, D).contiguous().float()
         dev = dx.device
+        _, G = self.arena.alloc(dev)
         for l in reversed(range(self.L)):
             k = f'l{l}.'
             st = 8 * (l + 1)
             xb, qkv, ctx, s1, m1, r1, x1b, a, g, s2, m2, r2 = saved['layers'][l]
-            # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g))
-            ds2, ds2b, G[k + 'o_ln.w'], G[k + 'o_ln.b'] = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True,
-                                                                          drop=Drop(pd, seed, st + 2), drop_mode=1)
-            _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU)
-            G[k + 'o_w'] = K.linear_dw(ds2b, g, M, D, I)
-            G[k + 'o_b'] = K.colsum_bf16(ds2b, M, D)
+            # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g));  bias grad of `dense` = colsum of the masked ds2
+            ds2, ds2b, _, _ = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 2), drop_mode=1,
+                                              dgamma=G[k + 'o_ln.w'], dbeta=G[k + 'o_ln.b'], dx_colsum=G[k + 'o_b'])
+            _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU, colsum=G[k + 'i_b'])
+            K.linear_dw(ds2b, g, M, D, I, out=G[k + 'o_w'], prezeroed=True)
             dx1, _ = K.linear_dx(da, W.s(k + 'i_w'), M, I, D, want_f32=True, residual=ds2)
-            G[k + 'i_w'] = K.linear_dw(da, x1b, M, I, D)
-            G[k + 'i_b'] = K.colsum_bf16(da, M, I)
+            K.linear_dw(da, x1b, M, I, D, out=G[k + 'i_w'], prezeroed=True)
             # attention-output LayerNorm:  x1 = LN(s1),  s1 = x + drop(dense(ctx))
-            ds1, ds1b, G[k + 'ao_ln.w'], G[k + 'ao_ln.b'] = K.layernorm_bwd(dx1, s1, m1, r1, W.p(k + 'ao_ln.w'), M, D, want_bf16=True,
-                                                                            drop=Drop(pd, seed, st + 1), drop_mode=1)
+            ds1, ds1b, _, _ = K.layernorm_bwd(dx1, s1, m1, r1, W.p(k + 'ao_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 1), drop_mode=1,
+                                              dgamma=G[k + 'ao_ln.w'], dbeta=G[k + 'ao_ln.b'], dx_colsum=G[k + 'ao_b'])
             _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
-            G[k + 'ao_w'] = K.linear_dw(ds1b, ctx, M, D, D)
-            G[k + 'ao_b'] = K.colsum_bf16(ds1b, M, D)
+            K.linear_dw(ds1b, ctx, M, D, D, out=G[k + 'ao_w'], prezeroed=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, S, S, D // H,
                             dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, kpm, Drop(pa, seed, st))
             dx, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True, residual=ds1)
-            G[k + 'qkv_w'] = K.linear_dw(dqkv, xb, M, 3 * D, D)
-            G[k + 'qkv_b'] = K.colsum_bf16(dqkv, M, 3 * D)
-        du, _, G['emb_ln.w'], G['emb_ln.b'] = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
-                                                              drop=Drop(pd, seed, 1), drop_mode=2)
-        G['word'] = torch.zeros_like(W.p('word'))
-        G['pos'] = torch.zeros_like(W.p('pos'))
-        G['type'] = torch.zeros_like(W.p('type'))
+            K.linear_dw(dqkv, xb, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=True)
+            K.colsum_bf16(dqkv, M, 3 * D, out=G[k + 'qkv_b'])
+        du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
+                                      drop=Drop(pd, seed, 1), drop_mode=2, dgamma=G['emb_ln.w'], dbeta=G['emb_ln.b'])
         K.roberta_embed_bwd(du, saved['ids'], saved['pos_ids'], G['word'], G['pos'], G['type'], B, S, D, self.pad)
         return G
 
@@ -181,6 +198,7 @@ class RobertaRunner:
 class CrossModalAttentionRunner:
     def __init__(self, W, D, heads, dropout, eps=1e-5):
         self.W, self.D, self.H, self.pd, self.eps = W, D, heads, dropout, eps
+        self.arena = GradArena(W.params)
 
     def forward(self, query, key_value, query_mask, kv_mask, training):
         """query [B,Sq,D] fp32, key_value [B,Skv,D] fp32; masks bool [B,S] (True = ignore) or None."""
@@ -220,23 +238,21 @@ class CrossModalAttentionRunner:
         S = saved
         B, Sq, Skv, seed, pd = S['B'], S['Sq'], S['Skv'], S['seed'], S['pd']
         M, Mv, Dh, I = B * Sq, B * Skv, D // H, 4 * D
-        G = {}
         dx3 = dout.reshape(M, D).contiguous().float()
         dev = dx3.device
-        ds3, ds3b, G['n3.w'], G['n3.b'] = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), M, D, want_bf16=True,
-                                                          drop=Drop(pd, seed, 6), drop_mode=1)
-        _, da = K.linear_dx(ds3b, W.s('ffn3_w'), M, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5))
-        G['ffn3_w'] = K.linear_dw(ds3b, S['g'], M, D, I)
-        G['ffn3_b'] = K.colsum_bf16(ds3b, M, D)
+        _, G = self.arena.alloc(dev)
+        ds3, ds3b, _, _ = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 6), drop_mode=1,
+                                          dgamma=G['n3.w'], dbeta=G['n3.b'], dx_colsum=G['ffn3_b'])
+        _, da = K.linear_dx(ds3b, W.s('ffn3_w'), M, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5),
+                            colsum=G['ffn0_b'])
+        K.linear_dw(ds3b, S['g'], M, D, I, out=G['ffn3_w'], prezeroed=True)
         dx2, _ = K.linear_dx(da, W.s('ffn0_w'), M, I, D, want_f32=True, residual=ds3)
-        G['ffn0_w'] = K.linear_dw(da, S['x2b'], M, I, D)
-        G['ffn0_b'] = K.colsum_bf16(da, M, I)
+        K.linear_dw(da, S['x2b'], M, I, D, out=G['ffn0_w'], prezeroed=True)
         # --- cross attention
-        ds2, ds2b, G['n2.w'], G['n2.b'] = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), M, D, want_bf16=True,
-                                                          drop=Drop(pd, seed, 4), drop_mode=1)
+        ds2, ds2b, _, _ = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 4), drop_mode=1,
+                                          dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'])
         _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
-        G['ca_out_w'] = K.linear_dw(ds2b, S['ctx2'], M, D, D)
-        G['ca_out_b'] = K.colsum_bf16(ds2b, M, D)
+        K.linear_dw(ds2b, S['ctx2'], M, D, D, out=G['ca_out_w'], prezeroed=True)
         dq2 = torch.empty((M, D), dtype=BF16, device=dev)
         dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
         kv2 = S['kv2']
@@ -244,29 +260,24 @@ class CrossModalAttentionRunner:
                         D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3))
         w_in = W.s('ca_in_w')
         dx1, _ = K.linear_dx(dq2, w_in[:D], M, D, D, want_f32=True, residual=ds2)
-        g_in_w = torch.empty((3 * D, D), dtype=F32, device=dev)
-        K.linear_dw(dq2, S['x1b'], M, D, D, out=g_in_w[:D])
-        K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=g_in_w[D:])
-        G['ca_in_w'] = g_in_w
-        g_in_b = torch.empty((3 * D,), dtype=F32, device=dev)
-        K.colsum_bf16(dq2, M, D, out=g_in_b[:D])
-        K.colsum_bf16(dkv2, Mv, 2 * D, out=g_in_b[D:])
-        G['ca_in_b'] = g_in_b
+        K.linear_dw(dq2, S['x1b'], M, D, D, out=G['ca_in_w'][:D], prezeroed=True)
+        K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=G['ca_in_w'][D:], prezeroed=True)
+        K.colsum_bf16(dq2, M, D, out=G['ca_in_b'][:D])
+        K.colsum_bf16(dkv2, Mv, 2 * D, out=G['ca_in_b'][D:])
         dkv = None
         if need_dkv:
             dkv, _ = K.linear_dx(dkv2, w_in[D:], Mv, 2 * D, D, want_f32=True)
             dkv = dkv.view(B, Skv, D)
         # --- self attention
-        ds1, ds1b, G['n1.w'], G['n1.b'] = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), M, D, want_bf16=True,
-                                                          drop=Drop(pd, seed, 2), drop_mode=1)
+        ds1, ds1b, _, _ = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 2), drop_mode=1,
+                                          dgamma=G['n1.w'], dbeta=G['n1.b'], dx_colsum=G['sa_out_b'])
         _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
-        G['sa_out_w'] = K.linear_dw(ds1b, S['ctx'], M, D, D)
-        G['sa_out_b'] = K.colsum_bf16(ds1b, M, D)
+        K.linear_dw(ds1b, S['ctx'], M, D, D, out=G['sa_out_w'], prezeroed=True)
         qkv = S['qkv']
         dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
         K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh,
                         dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, S['qm'], Drop(pd, seed, 1))
         dx, _ = K.linear_dx(dqkv, W.s('sa_in_w'), M, 3 * D, D, want_f32=True, residual=ds1)
-        G['sa_in_w'] = K.linear_dw(dqkv, S['xb'], M, 3 * D, D)
-        G['sa_in_b'] = K.colsum_bf16(dqkv, M, 3 * D)
+        K.linear_dw(dqkv, S['xb'], M, 3 * D, D, out=G['sa_in_w'], prezeroed=True)
+        K.colsum_bf16(dqkv, M, 3 * D, out=G['sa_in_b'])
         return G, dx.view(B, Sq, D), dkv

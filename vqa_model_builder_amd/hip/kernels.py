@@ -56,7 +56,7 @@ GEMM_PROFILE = None
 
 def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=None, pre_bf16=None, bias=None,
          residual=None, act_grad_of=None, act=ACT_NONE, act_bwd=ACT_NONE, drop: Drop = NO_DROP, allow_split_k=False,
-         split_k=0, tile_hint=0, ldc_f32=None, ldc_bf16=None, ld_pre=None, ld_res=None, ld_ag=None):
+         split_k=0, tile_hint=0, ldc_f32=None, ldc_bf16=None, ld_pre=None, ld_res=None, ld_ag=None, colsum=None, c_prezeroed=False):
     d = _gd
     d.a, d.b = _p(a), _p(b)
     d.M, d.N, d.K, d.lda, d.ldb, d.a_kc, d.b_kc = M, N, K, lda, ldb, int(a_kc), int(b_kc)
@@ -69,6 +69,7 @@ def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=N
     d.act, d.act_bwd, d.alpha = act, act_bwd, 1.0
     d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
     d.split_k, d.allow_split_k, d.tile_hint = split_k, int(allow_split_k), tile_hint
+    d.colsum, d.c_prezeroed = _p(colsum), int(c_prezeroed)
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -94,21 +95,24 @@ def linear_fwd(x_bf16, w_bf16, bias, M, N, K, *, want_f32=False, want_bf16=False
 
 
 def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, residual=None, act_grad_of=None,
-              act_bwd=ACT_NONE, drop: Drop = NO_DROP, ldw=None, ldy=None):
-    """dx[M,K] = (dy[M,N] W[N,K]) * act'(act_grad_of) * dropmask + residual."""
+              act_bwd=ACT_NONE, drop: Drop = NO_DROP, ldw=None, ldy=None, colsum=None):
+    """dx[M,K] = (dy[M,N] W[N,K]) * act'(act_grad_of) * dropmask + residual.  ``colsum`` (pre-zeroed [K] fp32) receives the
+    column sums of dx before the residual: the bias gradient of the Linear that produced the activation input."""
     dev = dy_bf16.device
     of = torch.empty((M, K), dtype=F32, device=dev) if want_f32 else None
     ob = torch.empty((M, K), dtype=BF16, device=dev) if want_bf16 else None
     gemm(dy_bf16, w_bf16, M, K, N, ldy or N, ldw or K, True, False, out_f32=of, out_bf16=ob, residual=residual,
-         act_grad_of=act_grad_of, act_bwd=act_bwd, drop=drop)
+         act_grad_of=act_grad_of, act_bwd=act_bwd, drop=drop, colsum=colsum)
     return of, ob
 
 
-def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None):
-    """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path)."""
+def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
+    """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path).  ``prezeroed``: ``out``
+    is known to be zero (gradient arena), so a split-K launch needs no memset."""
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=dy_bf16.device)
-    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True)
+        prezeroed = False
+    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed)
     return out
 
 
@@ -172,7 +176,7 @@ def layernorm_fwd(x, gamma, beta, rows, cols, *, add=None, want_f32=True, want_b
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=True, want_bf16=False, want_affine=True,
-                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None):
+                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None, dx_colsum=None):
     dev = dy.device
     dx = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
     dxb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
@@ -183,8 +187,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=T
         if dbeta is None:
             dbeta = torch.empty((cols,), dtype=F32, device=dev)
         ws = torch.empty((L().vqa_layernorm_bwd_ws_floats(cols),), dtype=F32, device=dev)
+    if ws is None and dx_colsum is not None:
+        ws = torch.empty((L().vqa_layernorm_bwd_ws_floats(cols),), dtype=F32, device=dev)
     _chk(L().vqa_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb), _p(dgamma), _p(dbeta),
-                               _p(ws), rows, cols, drop.p, drop.seed, drop.stream, drop_mode, _stream()), 'vqa_layernorm_bwd')
+                               _p(dx_colsum), _p(ws), rows, cols, drop.p, drop.seed, drop.stream, drop_mode, _stream()), 'vqa_layernorm_bwd')
     return dx, dxb, dgamma, dbeta
 
 

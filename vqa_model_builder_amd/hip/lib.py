@@ -17,7 +17,7 @@ class VqaGemmDesc(C.Structure):
                 ('pre_bf16', vp), ('ld_pre', i32), ('bias', vp), ('residual', vp), ('ld_res', i32),
                 ('act_grad_of', vp), ('ld_ag', i32), ('act', i32), ('act_bwd', i32), ('alpha', f32),
                 ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32),
-                ('split_k', i32), ('allow_split_k', i32), ('tile_hint', i32)]
+                ('split_k', i32), ('allow_split_k', i32), ('tile_hint', i32), ('colsum', vp), ('c_prezeroed', i32)]
 
 
 class VqaAttnDesc(C.Structure):
@@ -54,7 +54,7 @@ SIGNATURES = {
     'vqa_clip_assemble_bwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_layernorm_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, u64, u32, vp]),
     'vqa_layernorm_bwd_ws_floats': (sz, [i32]),
-    'vqa_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, u32, i32, vp]),
+    'vqa_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, u32, i32, vp]),
     'vqa_set_attention_mfma': (None, [i32]),
     'vqa_attention_fwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
     'vqa_attention_bwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
@@ -73,6 +73,9 @@ SIGNATURES = {
     'vqa_moe_route_weight_grad': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'vqa_randn_f32': (i32, [vp, u64, u64, u32, vp]),
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
+    'vqa_opt_chunk_elems': (i32, []),
+    'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
+    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
     'vqa_adamw_step': (i32, [C.POINTER(VqaAdamWDesc), vp]),
     'vqa_sumsq_f32': (i32, [vp, u64, vp, vp]),
 }

@@ -15,12 +15,19 @@ F32, BF16 = torch.float32, torch.bfloat16
 
 # ---- weight shadows for stand-alone parameters (version-checked bf16 copies) --------------------------------------
 _shadow_cache = {}
+_shadow_generation = 0
+
+
+def bump_shadow_generation():
+    """Called by optimisers that update parameters through raw pointers (no torch version-counter bump)."""
+    global _shadow_generation
+    _shadow_generation += 1
 
 
 def shadow_of(param: torch.Tensor) -> torch.Tensor:
     key = id(param)
     ent = _shadow_cache.get(key)
-    sig = (param.data_ptr(), param._version, param.device)
+    sig = (param.data_ptr(), param._version, param.device, _shadow_generation)
     if ent is None or ent[0] != sig or ent[2]() is not param:
         import weakref
         sh = K.cast_bf16(param.detach())
