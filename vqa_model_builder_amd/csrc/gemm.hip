@@ -40,7 +40,15 @@ struct GemmArgs {
     int k_per_split;                        // multiple of BK
     int group_m;                            // tile-row group of the L2-aware tile order (<= 1: plain row-major)
     float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
+#ifdef VQA_GEMM_TRACE
+    unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
+#endif
 };
+#ifdef VQA_GEMM_TRACE
+#define VQA_T(i) do { if (wave == 0) tr[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VQA_T(i) do { } while (0)
+#endif
 
 // ---- LDS addressing -------------------------------------------------------------------------------------------
 // KC tile: [ROWS][64] bf16, 128-B rows, 8 chunks of 16 B; chunk ^= (row>>1)&7  -> ds_read_b128 conflict-free
@@ -155,68 +163,92 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn)
     tn = r / rows;
 }
 
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane) {
-    // lane holds C[m][n..n+3], m = m_base + 16*i + (lane&15), n = n_base + 16*j + 4*(lane>>4)
+// Epilogue.  The MFMA leaves lane (r = lane&15, g = lane>>4) with C[16i + r][16j + 4g .. +3]: written straight out, every
+// store/load instruction touches 16 rows x 32 B (bf16) -- quarter cache lines, and the measured cost was 30-50 % of the
+// whole kernel.  Instead each wave turns its tile through a PRIVATE LDS scratch strip of 16 rows (no workgroup barrier):
+// afterwards lane l owns 4 consecutive columns 4*(l % LPR) of row l / LPR, so a wave instruction covers whole
+// 128/256-B row segments for every stream of the epilogue (bias, act_grad_of, pre_bf16, residual, c_f32, c_bf16).
+template <int TN> struct EpiScratch {
+    static constexpr int PITCH = TN * 64 + 16;           // bytes per scratch row: 16*TN fp32 + 16 B (bank spread)
+    static constexpr int BYTES = 16 * PITCH;             // per wave and 16-row strip
+};
+// strips of a wave tile that go through the scratch together: the largest power of two that fits `avail` bytes for NW waves
+template <int TM, int TN> constexpr int epi_group(int avail, int nw) {
+    int g = 1;
+    while (g * 2 <= TM && TM % (g * 2) == 0 && nw * g * 2 * EpiScratch<TN>::BYTES <= avail) g *= 2;
+    return g;
+}
+
+template <int TM, int TN, int G>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch) {
     const bool splitk = gridDim.z > 1;
+    if (splitk) {
+        // fp32 partials straight into the pre-zeroed C (lane holds C[m][n..n+3], m = 16i + (lane&15), n = 16j + 4*(lane>>4))
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m_base + 16 * i + (lane & 15);
-        const bool mok = m < p.M;
-        if (!mok && !p.colsum) continue;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + 16 * i + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n_base + 16 * j + 4 * (lane >> 4);
-            if (n >= p.N) continue;                       // N % 4 == 0 is enforced on the host; uniform per 16-lane group
-            f32x4 v = acc[i][j] * p.alpha;
-            if (splitk) {
-                if (mok) {
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_base + 16 * j + 4 * (lane >> 4);
+                if (m < p.M && n < p.N) {
                     float* dst = p.c_f32 + (size_t)m * p.ldc_f32 + n;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
-                }
-                continue;
-            }
-            if (mok) {
-                if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
-                if (p.act_grad_of) {
-                    const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
-                }
-                if (p.pre_bf16) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                    *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
-                }
-                if (p.act != ACT_NONE) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
-                }
-                if (p.drop_p > 0.f) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
-                }
-            } else {
-                v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            if (p.colsum) {
-                // every lane of the 16-lane group (rows m_base+16i+0..15, same 4 columns) takes part: sum over the rows by
-                // xor-shuffles inside the group, then ONE lane adds the 4 column sums (rows >= M contribute zeros)
-                f32x4 cs = v;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cs[r] += __shfl_xor(cs[r], o, 64);
-                }
-                if ((lane & 15) == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, cs[r]);
+                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r] * p.alpha);
                 }
             }
-            if (!mok) continue;
+        }
+        return;
+    }
+    constexpr int PITCH = EpiScratch<TN>::PITCH;
+    constexpr int LPR = 4 * TN;                          // lanes per row after the turn
+    constexpr int RPI = 64 / LPR;                        // rows per wave instruction
+    static_assert(TM % G == 0, "strip group must divide the wave tile");
+    const int wr_off = (lane & 15) * PITCH + (lane >> 4) * 16;
+    const int rd_row = lane / LPR, col = 4 * (lane % LPR);
+    const int n = n_base + col;
+    const bool nok = n < p.N;                            // N % 4 == 0 is enforced on the host
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += G) {
+        // G strips of 16 rows go through the scratch together (as many as the ring holds)
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * EpiScratch<TN>::BYTES + wr_off + j * 64) = acc[i0 + i][j] * p.alpha;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // NOT unrolled: the body carries every fused option; unrolled TM x 16/RPI times it was ~100 KB of once-executed code
+        // and the epilogue ran at instruction-fetch speed (measured 1000-1500 cycles per store instruction)
+#pragma unroll 1
+        for (int q = 0; q < G * 16 / RPI; ++q) {
+            const int row = q * RPI + rd_row;            // 0 .. 16 G - 1 (scratch rows are contiguous across the G strips)
+            f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + col * 4);
+            const int m = m_base + 16 * i0 + row;
+            if (m >= p.M || !nok) continue;
+            v += bv;
+            if (p.act_grad_of) {
+                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
+            }
+            if (p.pre_bf16) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+            }
+            if (p.act != ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+            }
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
+            }
+            cs += v;                                      // column sums of the stored values BEFORE the residual (bias gradient)
             if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
             if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
             if (p.c_bf16) {
@@ -225,6 +257,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
                 *reinterpret_cast<bf16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
             }
+        }
+        __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
+    }
+    if (p.colsum) {
+        // lanes l, l + LPR, l + 2 LPR ... hold the same 4 columns: fold them, then ONE lane per column group adds
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[r] += __shfl_xor(cs[r], o, 64);
+        }
+        if (lane < LPR && nok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, cs[r]);
         }
     }
 }
@@ -294,7 +339,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    static_assert(4 * EpiScratch<TN>::BYTES <= 2 * (A_BYTES + B_BYTES), "epilogue scratch does not fit the stage buffers");
+    constexpr int EG = epi_group<TM, TN>(2 * (A_BYTES + B_BYTES), 4);
+    gemm_epilogue<TM, TN, EG>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
 }
 
 // ================================================================================================================
@@ -305,14 +352,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 // and undone by the same XOR on the fragment reads.  Ragged edges: rows are clamped (their results are never stored),
 // k beyond K reads a zero page.
 // ================================================================================================================
-constexpr int BK1 = 32;
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
-// KC tile [ROWS][32] bf16: 64-B rows = 4 chunks, 4 rows per 256-B bank row.  ds_read_b128 is served in the lane groups
-// {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32): one group reads rows {0-3,12-15} at chunk c and rows {4-11} at chunk c^1,
-// so the XOR key must separate (row>>2) in {0,3} from {1,2}: key = ((row>>3)&1)<<1  (PMC: SQ_LDS_BANK_CONFLICT = 0).
+// KC tile of the BK=32 ring, [ROWS][32] bf16: 64-B rows = 4 chunks, 4 rows per 256-B bank row.  ds_read_b128 is served in
+// the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32): one group reads rows {0-3,12-15} at chunk c and rows {4-11}
+// at chunk c^1, so the XOR key must separate (row>>2) in {0,3} from {1,2}: key = ((row>>3)&1)<<1  (PMC: SQ_LDS_BANK_CONFLICT = 0).
+// The BK=64 ring uses the [ROWS][64] layout of the register-staged kernel (kc_off): 128-B rows = whole cache lines per row.
 __device__ __forceinline__ int kc1_key(int row) { return ((row >> 3) & 1) << 1; }
-__device__ __forceinline__ int kc1_off(int row, int chunk) { return row * 64 + ((chunk ^ kc1_key(row)) << 4); }
+template <int BKT> __device__ __forceinline__ int kcT_key(int row) { return BKT == 64 ? ((row >> 1) & 7) : kc1_key(row); }
+template <int BKT> __device__ __forceinline__ int kcT_off(int row, int chunk) { return row * (BKT * 2) + ((chunk ^ kcT_key<BKT>(row)) << 4); }
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -325,19 +373,20 @@ struct DmaLane {
     int kmax;                    // lane is inside K while tile_k0 < kmax (only consulted for the ragged last tile)
 };
 
-template <int ROWS, bool KC>
-__device__ __forceinline__ void dma_init(DmaLane (&d)[ROWS * 4 / 64 / 4], const bf16_t* __restrict__ g, int ld, int row0, int R,
+template <int ROWS, bool KC, int BKT, int NW>
+__device__ __forceinline__ void dma_init(DmaLane (&d)[ROWS * (BKT / 8) / 64 / NW], const bf16_t* __restrict__ g, int ld, int row0, int R,
                                          int kbeg, int kend, int wave, int lane) {
-    constexpr int PER_WAVE = ROWS * 4 / 64 / 4;
+    constexpr int PER_WAVE = ROWS * (BKT / 8) / 64 / NW;
+    constexpr int CPK = BKT / 8;                                  // 16-B chunks per k-contiguous row
     const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int pos = (wave * PER_WAVE + i) * 64 + lane;       // 16-B chunk index in LDS order
         if (KC) {
-            const int r = pos >> 2, c = (pos & 3) ^ kc1_key(r);
+            const int r = pos / CPK, c = (pos % CPK) ^ kcT_key<BKT>(r);
             const int gr = min(row0 + r, R - 1);
             d[i].ptr = reinterpret_cast<unsigned long long>(g + (size_t)gr * ld + kbeg + c * 8);
-            d[i].step = BK1 * 2;
+            d[i].step = BKT * 2;
             d[i].kmax = kend - c * 8;
         } else {
             constexpr int CPR = ROWS / 8;
@@ -345,7 +394,7 @@ __device__ __forceinline__ void dma_init(DmaLane (&d)[ROWS * 4 / 64 / 4], const 
             const int gr = row0 + c * 8;
             if (gr < R) {
                 d[i].ptr = reinterpret_cast<unsigned long long>(g + (size_t)(kbeg + krow) * ld + gr);
-                d[i].step = (unsigned long long)BK1 * ld * 2;
+                d[i].step = (unsigned long long)BKT * ld * 2;
                 d[i].kmax = kend - krow;
             } else { d[i].ptr = zero; d[i].step = 0; d[i].kmax = 0x7fffffff; }
         }
@@ -364,14 +413,16 @@ __device__ __forceinline__ void dma_issue(DmaLane (&d)[N_], char* lds_tile, int 
     }
 }
 
-// per-lane LDS byte offsets of the fragments of a wave tile, computed once (stage base is added as an immediate)
-template <int ROWS, bool KC, int NT>
+// per-lane LDS byte offsets of the fragments of a wave tile for k-substep 0, computed once.  KC: o1 = offset of substep 1
+// (BK=64 only: chunk index ^ 4, i.e. byte offset ^ 64).  RC: o0/o1 = the two transposing reads (k-rows q and q+4) of substep
+// 0; substep 1 lies 32 k-rows further (an immediate, the swizzle key ignores bit 5 of the k-row).
+template <int ROWS, bool KC, int BKT, int NT>
 __device__ __forceinline__ void frag_offsets(int (&o0)[NT], int (&o1)[NT], int r_base, int lane) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int r0 = r_base + 16 * t;
-        if (KC) { o0[t] = kc1_off(r0 + i, g); o1[t] = 0; }
+        if (KC) { o0[t] = kcT_off<BKT>(r0 + i, g); o1[t] = o0[t] ^ 64; }
         else {
             const int q = i >> 2, pp = i & 3, col = r0 + 4 * pp, krow = 8 * g + q;
             o0[t] = rc_off<ROWS>(krow, col >> 3) + ((col & 7) << 1);
@@ -380,11 +431,12 @@ __device__ __forceinline__ void frag_offsets(int (&o0)[NT], int (&o1)[NT], int r
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ bf16x8 load_frag1(const char* lds, int o0, int o1) {
-    if (KC) return *reinterpret_cast<const bf16x8*>(lds + o0);
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8 load_frag1(const char* lds, int o0, int o1, int s) {
+    if (KC) return *reinterpret_cast<const bf16x8*>(lds + (s ? o1 : o0));
+    constexpr int SUB = 32 * ROWS * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0 + s * SUB));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1 + s * SUB));
     union { struct { s16x4 a, b; } s; bf16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
@@ -392,30 +444,38 @@ __device__ __forceinline__ bf16x8 load_frag1(const char* lds, int o0, int o1) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int STAGES1, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NTHREADS) void gemm_v1_kernel(const GemmArgs p) {
-    constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_BYTES = BM * BK1 * 2, B_BYTES = BN * BK1 * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int PA = BM * 4 / 64 / 4, PB = BN * 4 / 64 / 4, GL = PA + PB;        // DMA instructions per wave per tile
-    __shared__ __attribute__((aligned(1024))) char smem[STAGES1 * STAGE_BYTES];
+// WM_ x WN_ waves, each a (BM/WM_) x (BN/WN_) wave tile; BKT = 32 or 64 elements of k per ring stage.
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p) {
+    constexpr int NW = WM_ * WN_;
+    constexpr int WTM = BM / WM_, WTN = BN / WN_, TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM * (BKT / 8) / 64 / NW, PB = BN * (BKT / 8) / 64 / NW, GL = PA + PB;   // DMA instructions per wave per tile
+    static_assert(PA >= 1 && PB >= 1, "tile too small for the wave count");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN_, wn = wave % WN_;
     int tm, tn;
     tile_coords<BM, BN>(p, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nk = (kend - kbeg + BK1 - 1) / BK1;
-    const int nk_full = (kend - kbeg) / BK1;                 // tiles entirely inside K: no per-lane k check needed
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
+    const int nk_full = (kend - kbeg) / BKT;                 // tiles entirely inside K: no per-lane k check needed
+#ifdef VQA_GEMM_TRACE
+    unsigned long long tr[32];
+    for (int i = 0; i < 32; ++i) tr[i] = 0;
+#endif
+    VQA_T(0);
 
     DmaLane da[PA], db[PB];
-    dma_init<BM, A_KC>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
-    dma_init<BN, B_KC>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+    dma_init<BM, A_KC, BKT, NW>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
+    dma_init<BN, B_KC, BKT, NW>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
     int ao0[TM], ao1[TM], bo0[TN], bo1[TN];
-    frag_offsets<BM, A_KC, TM>(ao0, ao1, wm * WTM, lane);
-    frag_offsets<BN, B_KC, TN>(bo0, bo1, wn * WTN, lane);
+    frag_offsets<BM, A_KC, BKT, TM>(ao0, ao1, wm * WTM, lane);
+    frag_offsets<BN, B_KC, BKT, TN>(bo0, bo1, wn * WTN, lane);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -426,11 +486,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v1_kernel(const GemmArgs p) {
     auto issue = [&](int t, int stage) {
         char* st = smem + stage * STAGE_BYTES;
         if (t < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
-        else { dma_issue<PA, true>(da, st, kbeg + t * BK1, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + t * BK1, wave); }
+        else { dma_issue<PA, true>(da, st, kbeg + t * BKT, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + t * BKT, wave); }
     };
 #pragma unroll
     for (int t = 0; t < STAGES1 - 1; ++t)
         if (t < nk) issue(t, t);
+    VQA_T(1);
 
     for (int kt0 = 0; kt0 < nk; kt0 += STAGES1) {
 #pragma unroll
@@ -440,23 +501,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_v1_kernel(const GemmArgs p) {
                 const int rem = min(nk - 1 - kt, STAGES1 - 2);   // younger tiles that may stay in flight
                 if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>(); else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; stage (s-1) is free again
+#ifdef VQA_GEMM_TRACE
+                if (kt < 24) VQA_T(2 + kt);
+#endif
                 if (kt + STAGES1 - 1 < nk) issue(kt + STAGES1 - 1, (s + STAGES1 - 1) % STAGES1);
                 const char* la = smem + s * STAGE_BYTES;
                 const char* lb = la + A_BYTES;
-                bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = load_frag1<A_KC>(la, ao0[i], ao1[i]);
+                for (int ks = 0; ks < BKT / 32; ++ks) {
+                    bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = load_frag1<B_KC>(lb, bo0[j], bo1[j]);
+                    for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, ao0[i], ao1[i], ks);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j) fb[j] = load_frag1<BN, B_KC>(lb, bo0[j], bo1[j], ks);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
-    gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    static_assert(NW * EpiScratch<TN>::BYTES <= STAGES1 * STAGE_BYTES, "epilogue scratch does not fit the ring");
+    __syncthreads();                                         // every wave is done with the ring: it becomes epilogue scratch
+    VQA_T(26);
+    constexpr int EG = epi_group<TM, TN>(STAGES1 * STAGE_BYTES, NW);
+    gemm_epilogue<TM, TN, EG>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
+#ifdef VQA_GEMM_TRACE
+    VQA_T(27);
+    wait_vmcnt<0>();
+    VQA_T(28);
+    if (p.trace && wave == 0 && lane == 0) {
+        tr[29] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+        tr[30] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        for (int i = 0; i < 32; ++i) p.trace[(size_t)blockIdx.x * 32 + i] = tr[i];
+    }
+#endif
 }
 
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
@@ -464,21 +545,39 @@ bool g_force_dma = false;
 int g_group_m = 16;
 int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
 
-template <int BM, int BN, int ST>
-int launch_v1s(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
+
+template <int BM, int BN, int WM_, int WN_, int BKT, int ST, bool AK, bool BKC>
+int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
+    constexpr int LDS = ST * (BM + BN) * BKT * 2;
+    static bool attr_set = false;
+    auto kern = gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC>;
+    if (!attr_set && LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    dim3 grid(tiles, 1, splits), block(NTHREADS);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, true, true>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, true, false>), grid, block, 0, st, p);
-    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, false, false>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_v1_kernel<BM, BN, ST, false, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p);
     return (int)hipGetLastError();
 }
-template <int BM, int BN>
+template <int BM, int BN, int WM_, int WN_, int BKT, int ST>
+int launch_v1s(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
+    if (a_kc && b_kc) return launch_v1k<BM, BN, WM_, WN_, BKT, ST, true, true>(p, splits, st);
+    if (a_kc && !b_kc) return launch_v1k<BM, BN, WM_, WN_, BKT, ST, true, false>(p, splits, st);
+    if (!a_kc && !b_kc) return launch_v1k<BM, BN, WM_, WN_, BKT, ST, false, false>(p, splits, st);
+    return launch_v1k<BM, BN, WM_, WN_, BKT, ST, false, true>(p, splits, st);
+}
+#ifdef VQA_GEMM_LAB
+}  // namespace
+#else
+// LDS-DMA rings in use: BK = 64 (whole 128-B lines per k-contiguous row), 2 or 3 stages.  (The BK = 32 rings of the first
+// version measured equal or slower on every shape of the path -- profiles/r01/gemm_tiles.log -- and are no longer built.)
+template <int BM, int BN, int WM_, int WN_>
 int launch_v1(const GemmArgs& p, int a_kc, int b_kc, int splits, int stages, hipStream_t st) {
-    if (stages == 2) return launch_v1s<BM, BN, 2>(p, a_kc, b_kc, splits, st);
-    if (stages == 3) return launch_v1s<BM, BN, 3>(p, a_kc, b_kc, splits, st);
-    return launch_v1s<BM, BN, 4>(p, a_kc, b_kc, splits, st);
+    if constexpr ((BM + BN) * 64 * 2 * 3 <= 160 * 1024 && BM * BN <= 128 * 64) {
+        if (stages >= 3) return launch_v1s<BM, BN, WM_, WN_, 64, 3>(p, a_kc, b_kc, splits, st);
+    }
+    return launch_v1s<BM, BN, WM_, WN_, 64, 2>(p, a_kc, b_kc, splits, st);
 }
 
 bool g_use_tr = true;
@@ -500,7 +599,11 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_group_m(int g) { g_group_m = g; }
-extern "C" void vqa_set_gemm_pipeline(int v1) { g_use_v1 = v1 != 0; g_force_dma = v1 != 0; g_v1_stages = (v1 >= 2 && v1 <= 4) ? v1 : 2; }
+extern "C" void vqa_set_gemm_pipeline(int v1) {
+    // diagnostics for tile_hint launches.  0: register-staged double buffer; 2 / 3: LDS-DMA ring with that many stages
+    g_use_v1 = v1 != 0; g_force_dma = v1 != 0;
+    g_v1_stages = v1 >= 3 ? 3 : 2;
+}
 
 extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -533,24 +636,25 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.colsum = d->colsum;
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
-    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128
+    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128, 6: 256x128 (8 waves)
     bool dma = g_use_v1;     // LDS-DMA pipeline vs register-staged double buffer
     int stages = g_v1_stages;
     if (d->tile_hint > 0) cfg = d->tile_hint - 1;
     else if (d->M <= 32) cfg = 2;
     else if (d->N <= 32) cfg = 3;
     else {
-        // Measured on MI355X (profiles/r01/gemm_tiles.log).  Every shape of the path is bound by the per-CU operand load
-        // path (L2/MALL -> LDS, ~45 GB/s/CU sustained), not by MFMA issue, so the choice trades bytes per FLOP (bigger
-        // tiles) against workgroups per CU (smaller tiles, shallower rings):
-        //   k-contiguous A and a wide N   -> 128x64 tiles, 2-stage LDS-DMA ring (half the A traffic, 4-5 WGs/CU)
-        //   k-contiguous operands, N=768  -> 64x64 LDS-DMA, 4-stage ring when K is long enough to fill it
-        //   transposed operands (dW, dX with N=768) -> 64x64 register-staged double buffer (ds_read_tr path)
+        // Measured on MI355X (profiles/r01/gemm_tiles.log, in-kernel timelines in profiles/r01/gemm_timeline.md).  The k loop
+        // of the LDS-DMA ring runs near the CU's L2->LDS rate; what is left is per-launch cost (cold start, C stores), so
+        // the choice is about workgroups per CU and bytes per FLOP:
+        //   k-contiguous A and a wide N (>= 1536)  -> 128x64 tiles, 2-stage ring (3 workgroups per CU)
+        //   everything else with >= 256 rows       -> 64x64 tiles; 3-stage ring when k is long (>= 2048) and both
+        //                                             operands are k-contiguous, else 2 stages
+        //   small M (< 256)                        -> 64x64 register-staged double buffer
         cfg = 1; dma = false;
         if (d->a_kc && d->M >= 512 && d->N >= 1536) { cfg = 4; dma = true; stages = 2; }
-        else if (d->a_kc && d->b_kc && d->M >= 512) { cfg = 1; dma = true; stages = d->K >= 2048 ? 4 : 2; }
+        else if (d->M >= 256 && d->N >= 64) { cfg = 1; dma = true; stages = (d->a_kc && d->b_kc && d->K >= 2048) ? 3 : 2; }
     }
-    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : 64;
+    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : 64;
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : 128;
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
 
@@ -571,12 +675,13 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         hipError_t e = hipMemset2DAsync(d->c_f32, (size_t)d->ldc_f32 * 4, 0, (size_t)d->N * 4, d->M, stream);
         if (e != hipSuccess) return (int)e;
     }
+    if (cfg == 6) return launch_v1<256, 128, 4, 2>(p, d->a_kc, d->b_kc, splits, 2, stream);
     if ((dma || g_force_dma) && g_use_tr && cfg != 2 && cfg != 3) {
         switch (cfg) {
-            case 0: return launch_v1<128, 128>(p, d->a_kc, d->b_kc, splits, stages, stream);
-            case 1: return launch_v1<64, 64>(p, d->a_kc, d->b_kc, splits, stages, stream);
-            case 4: return launch_v1<128, 64>(p, d->a_kc, d->b_kc, splits, stages, stream);
-            default: return launch_v1<64, 128>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            case 0: return launch_v1<128, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            case 1: return launch_v1<64, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            case 4: return launch_v1<128, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            default: return launch_v1<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
         }
     }
     switch (cfg) {
@@ -588,3 +693,4 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         default: return launch_cfg<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
     }
 }
+#endif  // VQA_GEMM_LAB
