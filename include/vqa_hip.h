@@ -194,8 +194,11 @@ typedef struct VqaOptJob {
  * tensor (the last one of a tensor fewer): one workgroup per chunk keeps the chip streaming whatever the tensor sizes. */
 int vqa_opt_chunk_elems(void);
 int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, float* norm2, vqa_stream_t s);
+/* hyper_dev (optional): device floats {lr, step}; when given they override lr and the two bias corrections (computed from
+ * step on the device), so a captured HIP graph of the optimiser step follows the schedule and the step count. */
 int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
-                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, vqa_stream_t s);
+                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* hyper_dev,
+                    vqa_stream_t s);
 /* sum of squares of a fp32 buffer accumulated into out[0] (atomic; caller zeroes) */
 int vqa_sumsq_f32(const float* x, uint64_t n, float* out, vqa_stream_t s);
 

@@ -68,7 +68,9 @@ __device__ __forceinline__ void row_softmax(const AttnArgs& a, const float* qrow
     }
 }
 
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs a_in) {
+    AttnArgs a = a_in;
+    if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pitch = a.Dh + 2;
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -101,7 +103,9 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs a) {
     }
 }
 
-__global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a_in) {
+    AttnArgs a = a_in;
+    if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pitch = a.Dh + 2, pp = a.Skv + 1;
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);

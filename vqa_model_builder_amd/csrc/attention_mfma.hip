@@ -115,7 +115,9 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MArgs a) {
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MArgs a_in) {
+    MArgs a = a_in;
+    if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
     constexpr int PITCH = DH * 2 + 16;
     __shared__ __attribute__((aligned(16))) char smem[3 * 64 * PITCH];
     char *Qs = smem, *Ks = smem + 64 * PITCH, *Vs = smem + 2 * 64 * PITCH;
@@ -148,7 +150,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MArgs a) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a) {
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
+    MArgs a = a_in;
+    if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
     constexpr int PITCH = DH * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *Qs = smem, *Ks = Qs + 64 * PITCH, *Vs = Ks + 64 * PITCH, *Gs = Vs + 64 * PITCH;

@@ -71,6 +71,19 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t stream, uint
 __device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
     return (rng_u32(seed, stream, idx) >> 8) * (1.0f / 16777216.0f);   // [0,1)
 }
+// INDIRECT seeds.  A seed with bit 63 set does not carry the key itself: bits 0..47 are the device address of a 64-bit
+// epoch word and bits 48..62 a call-site salt; the key is derived from the CURRENT value of that word.  A captured HIP
+// graph freezes every kernel argument, so this is how its replays still draw fresh dropout masks / router noise each
+// step (the training loop bumps the epoch word inside the graph); forward and backward of one step resolve the same key.
+// Kernels call this ONCE on entry (the seed is wave-uniform: one scalar load).
+__device__ __forceinline__ uint64_t resolve_seed(uint64_t s) {
+    if (s >> 63) {
+        const uint64_t e = *reinterpret_cast<const uint64_t*>(s & 0xFFFFFFFFFFFFull);
+        s = ((e + 1) * 0xD1342543DE82EF95ull) ^ (((s >> 48) & 0x7FFF) * 0x9E3779B97F4A7C15ull);
+        s &= 0x7FFFFFFFFFFFFFFFull;
+    }
+    return s;
+}
 // keep-scale for inverted dropout: 0 or 1/(1-p)
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t stream, uint64_t idx, float p, float inv_keep) {
     return rng_uniform(seed, stream, idx) >= p ? inv_keep : 0.f;

@@ -157,6 +157,7 @@ __global__ void clip_assemble_bwd_kernel(const float* __restrict__ du, bf16_t* _
 // dpre = dy * act'(pre) * dropmask(idx)   (backward of y = drop(act(pre)) when it is not fused into a GEMM epilogue)
 __global__ void act_drop_bwd_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ pre, int act, float* __restrict__ out,
                                     bf16_t* __restrict__ outb, size_t n, float p, float inv_keep, uint64_t seed, uint32_t stream) {
+    if (p > 0.f) seed = resolve_seed(seed);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float v = dy[i];
@@ -243,8 +244,16 @@ __global__ void sumsq_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
 
 // AdamW over every chunk; clip coefficient min(1, max_norm / (sqrt(norm2) + 1e-6)) computed on device
 // (torch.nn.utils.clip_grad_norm_ semantics); optionally refreshes the bf16 (or packed fp32) shadow of the parameter.
+// hyper (optional, device): {lr, step}: read at run time so a captured graph follows the schedule and the step count.
 __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uint32_t* __restrict__ chunks, const float* __restrict__ norm2,
-                                   float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+                                   float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2,
+                                   const float* __restrict__ hyper) {
+    if (hyper) {
+        lr = hyper[0];
+        const float t = hyper[1];
+        bc1 = 1.f - powf(beta1, t);
+        bc2 = 1.f - powf(beta2, t);
+    }
     const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
     const uint64_t beg = chunks[2 * blockIdx.x + 1];
     const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
@@ -298,10 +307,11 @@ int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
 }
 
 int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
-                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, vqa_stream_t s) {
+                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* hyper_dev,
+                    vqa_stream_t s) {
     if (!jobs_dev || !chunks_dev || nchunks <= 0) return VQA_ERR_ARG;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(TPB), 0, (hipStream_t)s, jobs_dev, chunks_dev, norm2, max_norm, lr, beta1, beta2,
-                       eps, bias_correction1, bias_correction2);
+                       eps, bias_correction1, bias_correction2, hyper_dev);
     return (int)hipGetLastError();
 }
 

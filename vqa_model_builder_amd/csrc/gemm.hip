@@ -275,7 +275,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool USE_TR>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p_in) {
+    GemmArgs p = p_in;
+    if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -446,7 +448,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // WM_ x WN_ waves, each a (BM/WM_) x (BN/WN_) wave tile; BKT = 32 or 64 elements of k per ring stage.
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p_in) {
+    GemmArgs p = p_in;
+    if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
     constexpr int NW = WM_ * WN_;
     constexpr int WTM = BM / WM_, WTN = BN / WN_, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, bf16_t* __restrict__ yb, float* __restrict__ mean_out, float* __restrict__ rstd_out,
     int rows, int cols, float eps, float drop_p, float inv_keep, uint64_t seed, uint32_t stream) {
+    if (drop_p > 0.f) seed = resolve_seed(seed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = cols / 4;
     for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx, bf16_t* __restrict__ dxb,
     float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode, int want_colsum) {
+    if (drop_p > 0.f) seed = resolve_seed(seed);
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [WAVES][3][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = cols / 4;

@@ -199,6 +199,7 @@ __global__ void aux_loss_kernel(const float* __restrict__ probs, const int64_t* 
 }
 
 __global__ void randn_kernel(float* __restrict__ out, uint64_t n, uint64_t seed, uint32_t stream) {
+    seed = resolve_seed(seed);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float u1 = (rng_u32(seed, stream, 2 * i) + 1.0f) * (1.0f / 4294967296.0f);     // (0,1]
@@ -209,6 +210,7 @@ __global__ void randn_kernel(float* __restrict__ out, uint64_t n, uint64_t seed,
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ yb, uint64_t n, float p, float inv_keep,
                                uint64_t seed, uint32_t stream) {
+    if (p > 0.f) seed = resolve_seed(seed);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float v = x[i] * (p > 0.f ? dropout_scale(seed, stream, i, p, inv_keep) : 1.f);

@@ -161,6 +161,7 @@ class GradReducer:
         self._presence.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
         pres_work = dist.all_reduce(self._presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         # pack + launch, bucket by bucket
+        self._static = []
         for b in self.buckets:
             srcs, dsts, zero_slots = [], [], []
             for p, off in zip(b.params, b.offsets):
@@ -170,6 +171,7 @@ class GradReducer:
                 else:
                     srcs.append(p.grad.reshape(-1))
                     dsts.append(view)
+            self._static.append((dsts, srcs, zero_slots))
             if zero_slots:
                 torch._foreach_zero_(zero_slots)
             if srcs:
@@ -177,6 +179,26 @@ class GradReducer:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         pres_work.wait()
         self._assign(self._presence.tolist())
+
+    @torch.no_grad()
+    def reduce_static(self):
+        """HIP-graph mode (graph.GraphedTrainStep): a replayed backward graph rewrites the SAME gradient buffers the last
+        ``reduce()`` packed from, while ``p.grad`` already points at the bucket slices the optimiser graph reads -- so pack
+        from the recorded sources, sum, average; nothing is re-pointed.  The set of present gradients is the capture's
+        (a captured step has no data-dependent control flow, so it cannot change)."""
+        if self.world == 1:
+            return
+        scale = 1.0 / self.world if self.average else 1.0
+        for b, (dsts, srcs, zero_slots) in zip(self.buckets, self._static):
+            if zero_slots:
+                torch._foreach_zero_(zero_slots)
+            if srcs:
+                torch._foreach_copy_(dsts, srcs)
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            b.work.wait()
+            if scale != 1.0:
+                b.flat.mul_(scale)
 
     def bytes_per_step(self) -> int:
         return sum(b.numel for b in self.buckets) * 4

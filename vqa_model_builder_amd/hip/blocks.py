@@ -17,8 +17,40 @@ from .kernels import Drop, NO_DROP
 F32, BF16 = torch.float32, torch.bfloat16
 
 
+_rng_epoch = None       # device int64 word behind INDIRECT seeds (HIP-graph mode), see csrc/common.h resolve_seed
+_rng_salt = 0
+
+
+def enable_indirect_seeds(device) -> torch.Tensor:
+    """Switches ``new_seed`` to INDIRECT seeds: bit 63 | 15-bit call-site salt << 48 | address of a device epoch word.
+    The kernels derive the key from the epoch word's CURRENT value, so a captured HIP graph (whose kernel arguments are
+    frozen) still draws fresh dropout masks every replay once ``advance_rng_epoch()`` is part of the graph."""
+    global _rng_epoch
+    if _rng_epoch is None or _rng_epoch.device != torch.device(device):
+        start = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFF      # honours torch.manual_seed
+        _rng_epoch = torch.full((1,), start, dtype=torch.int64, device=device)
+        assert _rng_epoch.data_ptr() < (1 << 48)
+    return _rng_epoch
+
+
+def disable_indirect_seeds():
+    global _rng_epoch
+    _rng_epoch = None
+
+
+def advance_rng_epoch():
+    """One device-side increment; call once per training step (inside the captured region in graph mode)."""
+    if _rng_epoch is not None:
+        _rng_epoch.add_(1)
+
+
 def new_seed() -> int:
-    """Per-forward dropout seed from torch's CPU generator (honours torch.manual_seed; no device sync)."""
+    """Per-forward dropout seed from torch's CPU generator (honours torch.manual_seed; no device sync); an INDIRECT
+    seed when ``enable_indirect_seeds`` is active."""
+    global _rng_salt
+    if _rng_epoch is not None:
+        _rng_salt = (_rng_salt + 1) & 0x7FFF
+        return (1 << 63) | (_rng_salt << 48) | _rng_epoch.data_ptr()
     return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
 
 
@@ -94,19 +126,19 @@ class ClipRunner:
         for l in reversed(range(self.L)):
             k = f'l{l}.'
             x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g = saved['layers'][l]
-            _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU, colsum=G[k + 'fc1_b'])
             K.linear_dw(dxb, g, M, D, I, out=G[k + 'fc2_w'], prezeroed=True)
-            dh2, _ = K.linear_dx(da, W.s(k + 'fc1_w'), M, I, D, want_f32=True)
+            _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU, colsum=G[k + 'fc1_b'])
             K.linear_dw(da, h2, M, I, D, out=G[k + 'fc1_w'], prezeroed=True)
+            dh2, _ = K.linear_dx(da, W.s(k + 'fc1_w'), M, I, D, want_f32=True)
             dx1, dx1b, _, _ = K.layernorm_bwd(dh2, x1, m2, r2, W.p(k + 'ln2.w'), M, D, dres=dx, want_bf16=True,
                                               dgamma=G[k + 'ln2.w'], dbeta=G[k + 'ln2.b'], dx_colsum=G[k + 'out_b'])
-            _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
             K.linear_dw(dx1b, ctx, M, D, D, out=G[k + 'out_w'], prezeroed=True)
+            _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dx.device)
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, T, T, D // H,
                             dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D)
-            dh1, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True)
             K.linear_dw(dqkv, h1, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=True)
+            dh1, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True)
             K.colsum_bf16(dqkv, M, 3 * D, out=G[k + 'qkv_b'])
             nxt = G[f'l{l - 1}.fc2_b'] if l > 0 else None                  # dx is the fc2 output gradient of the layer below
             dx, dxb, _, _ = K.layernorm_bwd(dh1, x, m1, r1, W.p(k + 'ln1.w'), M, D, dres=dx1, want_bf16=True,
@@ -116,6 +148,7 @@ class ClipRunner:
         dE = K.clip_assemble_bwd(du, B, P, D, G['cls'], G['pos'])
         Kp = saved['xp'].shape[1]
         K.linear_dw(dE, saved['xp'], B * P, D, Kp, out=G['patch_w'].view(D, Kp), prezeroed=True)
+        K.wgrad_join()
         return G
 
 
@@ -170,24 +203,25 @@ class RobertaRunner:
             # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g));  bias grad of `dense` = colsum of the masked ds2
             ds2, ds2b, _, _ = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 2), drop_mode=1,
                                               dgamma=G[k + 'o_ln.w'], dbeta=G[k + 'o_ln.b'], dx_colsum=G[k + 'o_b'])
-            _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU, colsum=G[k + 'i_b'])
             K.linear_dw(ds2b, g, M, D, I, out=G[k + 'o_w'], prezeroed=True)
-            dx1, _ = K.linear_dx(da, W.s(k + 'i_w'), M, I, D, want_f32=True, residual=ds2)
+            _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU, colsum=G[k + 'i_b'])
             K.linear_dw(da, x1b, M, I, D, out=G[k + 'i_w'], prezeroed=True)
+            dx1, _ = K.linear_dx(da, W.s(k + 'i_w'), M, I, D, want_f32=True, residual=ds2)
             # attention-output LayerNorm:  x1 = LN(s1),  s1 = x + drop(dense(ctx))
             ds1, ds1b, _, _ = K.layernorm_bwd(dx1, s1, m1, r1, W.p(k + 'ao_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 1), drop_mode=1,
                                               dgamma=G[k + 'ao_ln.w'], dbeta=G[k + 'ao_ln.b'], dx_colsum=G[k + 'ao_b'])
-            _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
             K.linear_dw(ds1b, ctx, M, D, D, out=G[k + 'ao_w'], prezeroed=True)
+            _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, S, S, D // H,
                             dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, kpm, Drop(pa, seed, st))
-            dx, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True, residual=ds1)
             K.linear_dw(dqkv, xb, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=True)
+            dx, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True, residual=ds1)
             K.colsum_bf16(dqkv, M, 3 * D, out=G[k + 'qkv_b'])
         du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
                                       drop=Drop(pd, seed, 1), drop_mode=2, dgamma=G['emb_ln.w'], dbeta=G['emb_ln.b'])
         K.roberta_embed_bwd(du, saved['ids'], saved['pos_ids'], G['word'], G['pos'], G['type'], B, S, D, self.pad)
+        K.wgrad_join()
         return G
 
 
@@ -243,24 +277,24 @@ class CrossModalAttentionRunner:
         _, G = self.arena.alloc(dev)
         ds3, ds3b, _, _ = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 6), drop_mode=1,
                                           dgamma=G['n3.w'], dbeta=G['n3.b'], dx_colsum=G['ffn3_b'])
+        K.linear_dw(ds3b, S['g'], M, D, I, out=G['ffn3_w'], prezeroed=True)
         _, da = K.linear_dx(ds3b, W.s('ffn3_w'), M, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5),
                             colsum=G['ffn0_b'])
-        K.linear_dw(ds3b, S['g'], M, D, I, out=G['ffn3_w'], prezeroed=True)
-        dx2, _ = K.linear_dx(da, W.s('ffn0_w'), M, I, D, want_f32=True, residual=ds3)
         K.linear_dw(da, S['x2b'], M, I, D, out=G['ffn0_w'], prezeroed=True)
+        dx2, _ = K.linear_dx(da, W.s('ffn0_w'), M, I, D, want_f32=True, residual=ds3)
         # --- cross attention
         ds2, ds2b, _, _ = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 4), drop_mode=1,
                                           dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'])
-        _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
         K.linear_dw(ds2b, S['ctx2'], M, D, D, out=G['ca_out_w'], prezeroed=True)
+        _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
         dq2 = torch.empty((M, D), dtype=BF16, device=dev)
         dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
         kv2 = S['kv2']
         K.attention_bwd(S['q2'], kv2[:, :D], kv2[:, D:], dctx2, D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, dq2, dkv2[:, :D], dkv2[:, D:],
                         D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3))
         w_in = W.s('ca_in_w')
-        dx1, _ = K.linear_dx(dq2, w_in[:D], M, D, D, want_f32=True, residual=ds2)
         K.linear_dw(dq2, S['x1b'], M, D, D, out=G['ca_in_w'][:D], prezeroed=True)
+        dx1, _ = K.linear_dx(dq2, w_in[:D], M, D, D, want_f32=True, residual=ds2)
         K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=G['ca_in_w'][D:], prezeroed=True)
         K.colsum_bf16(dq2, M, D, out=G['ca_in_b'][:D])
         K.colsum_bf16(dkv2, Mv, 2 * D, out=G['ca_in_b'][D:])
@@ -271,13 +305,14 @@ class CrossModalAttentionRunner:
         # --- self attention
         ds1, ds1b, _, _ = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 2), drop_mode=1,
                                           dgamma=G['n1.w'], dbeta=G['n1.b'], dx_colsum=G['sa_out_b'])
-        _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
         K.linear_dw(ds1b, S['ctx'], M, D, D, out=G['sa_out_w'], prezeroed=True)
+        _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
         qkv = S['qkv']
         dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
         K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh,
                         dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, S['qm'], Drop(pd, seed, 1))
-        dx, _ = K.linear_dx(dqkv, W.s('sa_in_w'), M, 3 * D, D, want_f32=True, residual=ds1)
         K.linear_dw(dqkv, S['xb'], M, 3 * D, D, out=G['sa_in_w'], prezeroed=True)
+        dx, _ = K.linear_dx(dqkv, W.s('sa_in_w'), M, 3 * D, D, want_f32=True, residual=ds1)
         K.colsum_bf16(dqkv, M, 3 * D, out=G['sa_in_b'])
+        K.wgrad_join()
         return G, dx.view(B, Sq, D), dkv

@@ -106,12 +106,50 @@ def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, resi
     return of, ob
 
 
+# ---- weight-gradient side stream ---------------------------------------------------------------------------------
+# Nothing in a backward pass waits for a weight gradient (only the optimiser does), while the dX chain is a string of
+# short dependent launches that each leave CUs idle (cold start, C-tile stores).  With WGRAD_SIDE_STREAM on, every
+# linear_dw goes to a side HIP stream that waits on an event recorded after its operands' producers; the block runner joins
+# it at the end of its backward.  Worth it when launches are free (captured into a HIP graph: graph.GraphedTrainStep turns
+# it on); in eager mode the extra event traffic costs host time.  Operands are kept alive until the join, so the caching
+# allocator never hands their memory to the main stream while the side stream still reads it.
+WGRAD_SIDE_STREAM = False
+_wgrad = {}          # main cuda_stream handle -> [side torch.cuda.Stream, keep-alive list]
+
+
+def _wgrad_slot():
+    cur = torch.cuda.current_stream()
+    slot = _wgrad.get(cur.cuda_stream)
+    if slot is None:
+        slot = _wgrad[cur.cuda_stream] = [torch.cuda.Stream(), []]
+    return cur, slot
+
+
+def wgrad_join():
+    """Makes the current stream wait for the weight-gradient GEMMs its side stream still runs (end of a block backward)."""
+    if not _wgrad:
+        return
+    cur = torch.cuda.current_stream()
+    slot = _wgrad.get(cur.cuda_stream)
+    if slot is not None and slot[1]:
+        cur.wait_stream(slot[0])
+        slot[1].clear()
+
+
 def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
     """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path).  ``prezeroed``: ``out``
     is known to be zero (gradient arena), so a split-K launch needs no memset."""
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=dy_bf16.device)
         prezeroed = False
+    if WGRAD_SIDE_STREAM and GEMM_PROFILE is None:
+        cur, slot = _wgrad_slot()
+        side = slot[0]
+        side.wait_stream(cur)                      # operands (and the zero-filled arena) are ready at this point of the main stream
+        with torch.cuda.stream(side):
+            gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed)
+        slot[1].extend((dy_bf16, x_bf16, out))
+        return out
     gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed)
     return out
 

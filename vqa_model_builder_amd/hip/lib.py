@@ -75,7 +75,7 @@ SIGNATURES = {
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
-    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp]),
+    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
     'vqa_adamw_step': (i32, [C.POINTER(VqaAdamWDesc), vp]),
     'vqa_sumsq_f32': (i32, [vp, u64, vp, vp]),
 }

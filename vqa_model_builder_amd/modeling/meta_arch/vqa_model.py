@@ -356,8 +356,25 @@ class VietnameseVQAModel(nn.Module):
 
     def forward(self, pixel_values, input_ids, attention_mask, questions: Optional[List[str]] = None,
                 labels: Optional[torch.Tensor] = None, return_features: bool = False) -> VQAOutput:
-        visual_pooled, visual_spatial = self.encode_visual(pixel_values)
-        text_pooled, text_sequence = self.encode_text(input_ids, attention_mask)
+        if getattr(self, 'parallel_towers', False) and pixel_values.is_cuda:
+            # The two encoders share nothing until the fusion: run the vision tower on a side HIP stream (its backward
+            # follows it there -- autograd replays every node on its forward stream).  A single short GEMM leaves most CUs
+            # idle during its cold start and its C-tile stores; a second independent launch chain fills them.  Captured
+            # into a HIP graph (graph.GraphedTrainStep) the two chains become parallel branches at no host cost.
+            main = torch.cuda.current_stream()
+            if getattr(self, '_tower_stream', None) is None:
+                self._tower_stream = torch.cuda.Stream()
+            side = self._tower_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                visual_pooled, visual_spatial = self.encode_visual(pixel_values)
+            text_pooled, text_sequence = self.encode_text(input_ids, attention_mask)
+            main.wait_stream(side)
+            for t in (visual_pooled, visual_spatial):
+                t.record_stream(main)
+        else:
+            visual_pooled, visual_spatial = self.encode_visual(pixel_values)
+            text_pooled, text_sequence = self.encode_text(input_ids, attention_mask)
         fused = self.fusion(visual_spatial, text_sequence, text_mask=~attention_mask.bool())
         moe_info = None
         if self.moe_layer is not None:

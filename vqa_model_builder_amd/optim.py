@@ -24,11 +24,52 @@ class FusedAdamW(torch.optim.Optimizer):
         self._shadow_sets = []
         self._tables = {}
         self._norm2 = None
+        self._hyper = None                                # HIP-graph mode: per group device floats {lr, step}
+        self._hyper_inc = None
+        self._pending_replays = 0
+        self._staging = {}                                # HIP-graph mode: pinned host rows per job table
 
     def attach_shadows(self, model):
         """Lets the update kernel write the bf16 / packed-fp32 weight shadows of the block runners directly."""
         self._shadow_sets = [m._W.shadows for m in model.modules() if hasattr(m, '_W')]
         return self
+
+    def make_capturable(self, device):
+        """HIP-graph mode: learning rate and step count live in device memory ({lr, step} per group), are advanced by a
+        device-side add that is part of the captured step, and the update kernel derives the bias corrections from them
+        -- a replayed graph then follows the schedule instead of repeating the captured step's constants.  Call before
+        the capture, after any eager warm-up steps; all parameters of a group must share one step count."""
+        self._hyper = []
+        for group in self.param_groups:
+            steps = {int(self.state[p]['step']) for p in group['params'] if p in self.state and self.state[p]}
+            if len(steps) > 1:
+                raise RuntimeError('FusedAdamW.make_capturable: parameters of one group have different step counts')
+            self._hyper.append(torch.tensor([float(group['lr']), float(steps.pop() if steps else 0)], dtype=torch.float32).to(device))
+        self._hyper_inc = torch.tensor([0.0, 1.0], dtype=torch.float32).to(device)
+        self._staging = {slot: torch.empty(tuple(c[1].shape), dtype=torch.int64).pin_memory() for slot, c in self._tables.items()}
+        return self
+
+    def refresh_lr(self):
+        """Copies the groups' current ``lr`` to the device words (call between replays when a scheduler changed it)."""
+        if self._hyper is not None:
+            for group, h in zip(self.param_groups, self._hyper):
+                h[0:1].fill_(float(group['lr']))
+
+    def note_replays(self, n=1):
+        """A captured step was replayed ``n`` times: the python-side ``state[p]['step']`` counters catch up lazily."""
+        self._pending_replays += n
+
+    def sync_step_counts(self):
+        if self._pending_replays:
+            for group in self.param_groups:
+                for p in group['params']:
+                    if p in self.state and self.state[p]:
+                        self.state[p]['step'] = int(self.state[p]['step']) + self._pending_replays
+            self._pending_replays = 0
+
+    def state_dict(self):
+        self.sync_step_counts()
+        return super().state_dict()
 
     def _shadow_map(self):
         out = {}
@@ -43,6 +84,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        self.sync_step_counts()
         lib, st = K.L(), K._stream()
         shadows = self._shadow_map()
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
@@ -78,19 +120,35 @@ class FusedAdamW(torch.optim.Optimizer):
             if cached is None or cached[0] != key:
                 ch = lib.vqa_opt_chunk_elems()
                 chunks = [(ji, off) for ji, r in enumerate(rows) for off in range(0, r[5], ch)]
-                cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks))
+                stage = self._staging.get(slot)
+                if stage is not None and cached is not None and stage.shape[0] == len(rows) and cached[3] == len(chunks):
+                    # HIP-graph mode: same tensors, new addresses (gradients allocated from the graph's pool).  No
+                    # allocation is legal inside a stream capture: refill the pre-pinned staging rows and copy them
+                    # over the existing device table (a memcpy node that replays harmlessly).
+                    stage.copy_(torch.tensor(rows, dtype=torch.int64))
+                    cached[1].copy_(stage, non_blocking=True)
+                    cached = (key, cached[1], cached[2], cached[3])
+                else:
+                    cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks))
                 self._tables[slot] = cached
-            tables.append((self.param_groups[gi], step, cached[1], cached[2], cached[3]))
+            tables.append((self.param_groups[gi], step, cached[1], cached[2], cached[3], gi))
+        if self._hyper is not None and len(tables) != len({t[5] for t in tables}):
+            raise RuntimeError('FusedAdamW (capturable): parameters of one group have different step counts')
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if clip:
             self._norm2.zero_()
-            for _, _, tab, chunks, nch in tables:
+            for _, _, tab, chunks, nch, _ in tables:
                 K._chk(lib.vqa_sumsq_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr(), st), 'vqa_sumsq_multi')
-        for group, step, tab, chunks, nch in tables:
+        for group, step, tab, chunks, nch, gi in tables:
             b1, b2 = group['betas']
+            hyper = None
+            if self._hyper is not None:
+                hyper = self._hyper[gi]
+                hyper.add_(self._hyper_inc)               # device-side step += 1 (captured with the step)
             K._chk(lib.vqa_adamw_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr() if clip else None,
                                        float(self.max_grad_norm or 0.0), float(group['lr']), b1, b2, group['eps'],
-                                       1.0 - b1 ** step, 1.0 - b2 ** step, st), 'vqa_adamw_multi')
+                                       1.0 - b1 ** step, 1.0 - b2 ** step, hyper.data_ptr() if hyper is not None else None, st),
+                   'vqa_adamw_multi')
         _ops.bump_shadow_generation()                      # stand-alone bf16 shadows (tail ops) are stale now
         return loss
 
