@@ -433,15 +433,32 @@ __device__ __forceinline__ void frag_offsets(int (&o0)[NT], int (&o1)[NT], int r
     }
 }
 
+// Fragment reads of the LDS-DMA ring.  KC: a plain ds_read_b128 (the compiler tracks its lgkmcnt).  RC: the transposing read
+// is issued through INLINE ASM: behind the builtin, the compiler cannot prove that the read does not alias the LDS
+// writes of the global_load_lds still in flight (other ring stages) and drains the whole DMA queue first
+// (s_waitcnt vmcnt(0) before every fragment group -- measured: the ring ran with no overlap at all, 1430 cycles per k-step
+// whatever its depth).  The asm reads are invisible to the compiler's counters, so the caller closes each group with
+// frag_fence(): s_waitcnt lgkmcnt(0) plus a register dependency that keeps the MFMAs behind it.
 template <int ROWS, bool KC>
 __device__ __forceinline__ bf16x8 load_frag1(const char* lds, int o0, int o1, int s) {
     if (KC) return *reinterpret_cast<const bf16x8*>(lds + (s ? o1 : o0));
     constexpr int SUB = 32 * ROWS * 2;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0 + s * SUB));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1 + s * SUB));
+    const unsigned base = (unsigned)(uintptr_t)lds + s * SUB;       // low 32 bits of a flat LDS address = LDS byte offset
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(base + o0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(base + o1));
     union { struct { s16x4 a, b; } s; bf16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
+}
+template <bool ANY_RC, int NA, int NB>
+__device__ __forceinline__ void frag_fence(bf16x8 (&fa)[NA], bf16x8 (&fb)[NB]) {
+    if (!ANY_RC) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(fb[j]));
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -456,6 +473,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int PA = BM * (BKT / 8) / 64 / NW, PB = BN * (BKT / 8) / 64 / NW, GL = PA + PB;   // DMA instructions per wave per tile
     static_assert(PA >= 1 && PB >= 1, "tile too small for the wave count");
+    static_assert(STAGES1 >= 2 && STAGES1 <= 6 && (STAGES1 - 2) * GL <= 63, "ring depth: vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -503,7 +521,11 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
             const int kt = kt0 + s;
             if (kt < nk) {
                 const int rem = min(nk - 1 - kt, STAGES1 - 2);   // younger tiles that may stay in flight
-                if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>(); else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>(); else wait_vmcnt<0>();
+                if (STAGES1 >= 6 && rem >= 4) wait_vmcnt<4 * GL>();
+                else if (STAGES1 >= 5 && rem >= 3) wait_vmcnt<3 * GL>();
+                else if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>();
+                else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>();
+                else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();                // tile kt landed for every wave; stage (s-1) is free again
 #ifdef VQA_GEMM_TRACE
                 if (kt < 24) VQA_T(2 + kt);
@@ -518,6 +540,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
                     for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, ao0[i], ao1[i], ks);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[j] = load_frag1<BN, B_KC>(lb, bo0[j], bo1[j], ks);
+                    frag_fence<!A_KC || !B_KC>(fa, fb);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -651,12 +674,15 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         // of the LDS-DMA ring runs near the CU's L2->LDS rate; what is left is per-launch cost (cold start, C stores), so
         // the choice is about workgroups per CU and bytes per FLOP:
         //   k-contiguous A and a wide N (>= 1536)  -> 128x64 tiles, 2-stage ring (3 workgroups per CU)
-        //   everything else with >= 256 rows       -> 64x64 tiles; 3-stage ring when k is long (>= 2048) and both
-        //                                             operands are k-contiguous, else 2 stages
+        //   everything else with >= 256 rows       -> 64x64 tiles; 3-stage ring when k is long (>= 2048) and the grid is
+        //                                             under two workgroups per CU (else the third stage costs occupancy)
         //   small M (< 256)                        -> 64x64 register-staged double buffer
         cfg = 1; dma = false;
         if (d->a_kc && d->M >= 512 && d->N >= 1536) { cfg = 4; dma = true; stages = 2; }
-        else if (d->M >= 256 && d->N >= 64) { cfg = 1; dma = true; stages = (d->a_kc && d->b_kc && d->K >= 2048) ? 3 : 2; }
+        else if (d->M >= 256 && d->N >= 64) {
+            cfg = 1; dma = true;
+            stages = (d->K >= 2048 && (long)ceil_div(d->M, 64) * ceil_div(d->N, 64) < 512) ? 3 : 2;
+        }
     }
     const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : 64;
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : 128;
