@@ -57,6 +57,16 @@ typedef struct VqaGemmDesc {
     int c_prezeroed;                       /* split-K only: c_f32 is already zero, skip the memset */
 } VqaGemmDesc;
 int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream);
+
+/* Up to 32 independent GEMMs C_i[M_i,N_i] (fp32, plain store) = A_i B_i^T of ONE operand layout in one launch: the
+ * weight-gradient GEMMs of a backward pass (dW = dY^T X: a_kc = b_kc = 0), which nothing but the optimiser waits for and
+ * which the block runners therefore queue and issue together -- one cold start and one tail for all of them, thousands of
+ * equal tiles to balance over the CUs.  Same tile kernel and numerics as vqa_gemm_bf16 (64x64 LDS-DMA ring, no split-K). */
+typedef struct VqaGemmGroupItem {
+    const void* a; const void* b; float* c_f32;
+    int M, N, K, lda, ldb, ldc;
+} VqaGemmGroupItem;
+int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
 void vqa_set_gemm_group_m(int g);          /* tile-row group of the L2-aware tile order (default 16; <= 1 = row-major) */
 void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */
@@ -99,7 +109,11 @@ int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, cons
  *              whose gradient it is (x = r + dropout(t): dx_bf16 is dt); dx_f32 stays unmasked (dr).
  * drop_mode 2: dy is masked on load (forward was y = dropout(LN(x)) with the same drop_* at index row*cols+c).
  * dx_colsum (optional, [cols]): column sums of the (masked) gradient that dx_bf16 holds = the bias gradient of the
- *              Linear whose output was added into x; fused here so no separate pass over dx is needed.  cols <= 3328. */
+ *              Linear whose output was added into x; fused here so no separate pass over dx is needed.  cols <= 3328.
+ * ws == NULL with dgamma / dbeta / dx_colsum given = ACCUMULATE mode: the per-workgroup partial sums are added to the
+ *              outputs with fp32 atomics (outputs must be initialised).  One launch instead of two, but 256 workgroups
+ *              adding to the same 3*cols addresses measured 3x SLOWER than the two-pass form on MI355X (34.9 vs 11.7 + 8.2
+ *              us at 2048 x 768): only worth it for short inputs; the block runners use the two-pass form (ws != NULL). */
 size_t vqa_layernorm_bwd_ws_floats(int cols);
 int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum,
@@ -119,6 +133,10 @@ typedef struct VqaAttnDesc {
     /* backward only */
     const void* d_o; int ldd_o;
     void* dq; void* dk; void* dv; int lddq, lddk, lddv;
+    /* optional, backward: fp32 [H*Dh] each, ACCUMULATED into (must be initialised, e.g. zero-filled arena slots): column
+     * sums over all B*S rows of the bf16 dq / dk / dv written above = the bias gradients of the Q/K/V projections, fused so
+     * that no separate pass re-reads the three tensors. */
+    float* dq_colsum; float* dk_colsum; float* dv_colsum;
 } VqaAttnDesc;
 int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s);
 void vqa_set_attention_mfma(int on);       /* 1 (default): MFMA kernel for Sq,Skv <= 64, Dh in {32,64,96,128}; 0: generic kernel only */

@@ -395,3 +395,32 @@ def test_fused_adamw_matches_torch():
     for a, b in zip(ref, mine):
         if o_ref.state[a]:
             assert torch.allclose(o_ref.state[a]['exp_avg_sq'], o_mine.state[b]['exp_avg_sq'], atol=1e-8, rtol=1e-5)
+
+
+def test_grouped_weight_gradient_gemm_matches_single_launches():
+    """vqa_gemm_bf16_grouped (queued linear_dw + wgrad_join) against the same GEMMs launched one by one, bit for bit
+    (same tile kernel, same k order), on ragged token counts and mixed output shapes."""
+    from vqa_model_builder_amd.hip import kernels as K
+    torch.manual_seed(3)
+    shapes = [(2048, 768, 768), (2048, 2304, 768), (1600, 768, 3072), (200, 64, 128), (72, 136, 72)]
+    dys = [torch.randn(m, n, device='cuda').to(torch.bfloat16) for m, n, k in shapes]
+    xs = [torch.randn(m, k, device='cuda').to(torch.bfloat16) for m, n, k in shapes]
+    prev = K.WGRAD_GROUPED
+    try:
+        K.WGRAD_GROUPED = False
+        ref = [torch.full((n, k), float('nan'), device='cuda') for m, n, k in shapes]
+        for (m, n, k), dy, x, o in zip(shapes, dys, xs, ref):
+            K.linear_dw(dy, x, m, n, k, out=o)
+        K.WGRAD_GROUPED = True
+        got = [torch.full((n, k), float('nan'), device='cuda') for m, n, k in shapes]
+        for (m, n, k), dy, x, o in zip(shapes, dys, xs, got):
+            K.linear_dw(dy, x, m, n, k, out=o)
+        K.wgrad_join()
+        torch.cuda.synchronize()
+        for (m, n, k), dy, x, r, g in zip(shapes, dys, xs, ref, got):
+            exact = dy.float().t() @ x.float()
+            assert torch.isfinite(g).all()
+            assert (g - exact).norm() / exact.norm() < 1e-5
+            assert (g - r).abs().max() <= 1e-4 * exact.abs().max()       # single launches may pick split-K (atomics): not bitwise
+    finally:
+        K.WGRAD_GROUPED = prev

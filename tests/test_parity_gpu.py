@@ -113,7 +113,9 @@ def run_case(tag, rich, with_oracle=False):
         num += (es * ref_n) ** 2
         env_num += (env * ref_n) ** 2
         den += ref_n ** 2
-        assert en <= NORM_TOL, (tag, name, 'gradient norm', en)
+        # norm of each gradient: fixed tolerance, widened for the parameters whose gradient the bf16 emulation itself moves by
+        # more (the router gate of the full-size MoE config: emulation envelope 0.12 on a norm of 1.45)
+        assert en <= max(NORM_TOL, ENV * env), (tag, name, 'gradient norm', en, env)
     report['grad_global_rel_l2'] = float(np.sqrt(num / den))
     report['grad_global_envelope'] = float(np.sqrt(env_num / den))
     report['grad_worst_rel_l2'], report['grad_worst_name'], report['gnorm_worst_rel'] = worst_g, worst_name, worst_n

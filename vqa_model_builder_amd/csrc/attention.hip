@@ -242,7 +242,13 @@ int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s) {
         attr = LDS_MAX;
     }
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(NT), lds, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    rc = (int)hipGetLastError();
+    // the generic kernel does not fuse the bias-gradient column sums: separate passes (outputs are zero on entry by contract)
+    const int HD = d->H * d->Dh;
+    if (!rc && d->dq_colsum) rc = vqa_colsum_bf16(d->dq, d->B * d->Sq, HD, d->lddq, d->dq_colsum, s);
+    if (!rc && d->dk_colsum) rc = vqa_colsum_bf16(d->dk, d->B * d->Skv, HD, d->lddk, d->dk_colsum, s);
+    if (!rc && d->dv_colsum) rc = vqa_colsum_bf16(d->dv, d->B * d->Skv, HD, d->lddv, d->dv_colsum, s);
+    return rc;
 }
 
 }  // extern "C"

@@ -24,7 +24,23 @@ struct MArgs {
     const uint8_t* mask;
     float scale, drop_p, inv_keep;
     uint64_t seed; uint32_t stream;
+    float *dq_cs, *dk_cs, *dv_cs;       // optional bias-gradient accumulators [H*Dh]
 };
+
+// column sums of one wave's 16 x 4 slab (lane (i, g) holds row i, columns 4g..4g+3 of the bf16 values it just stored):
+// fold the 16 row-lanes; lanes i == 0 leave their 4 columns in the wave's LDS row.  The workgroup's four rows are summed
+// at the end and added to the accumulator ONCE per workgroup: B adders per address (one per batch element), inside the
+// range where float atomics keep their rate (per-wave adds -- 4 B adders -- ran the kernel 2.4x slower).
+__device__ __forceinline__ void slab_colsum(float* lds_row, const bf16x4& v, bool row_ok, int lane) {
+    f32x4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = row_ok ? (float)v[r] : 0.f;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] += __shfl_xor(c[r], o, 64);
+    if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(lds_row) = c;
+}
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int PT = 144;          // pitch of the [kv][q] P^T / dS^T tiles (64 bf16 + 16 B)
@@ -157,6 +173,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *Qs = smem, *Ks = Qs + 64 * PITCH, *Vs = Ks + 64 * PITCH, *Gs = Vs + 64 * PITCH;
     char *Pt = Gs + 64 * PITCH, *Dt = Pt + 64 * PT;                  // [kv][q] bf16 tiles
+    __shared__ __attribute__((aligned(16))) float cs_part[3][4][DH];  // bias-gradient partials: {dq, dk, dv} x wave x column
+    const bool want_cs = a.dq_cs || a.dk_cs || a.dv_cs;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
     stage_tile<DH>(Qs, a.q + (size_t)b * a.Sq * a.ldq + h * DH, a.Sq, a.ldq, tid);
@@ -206,12 +224,11 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Ks, PITCH, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, lane), df[u], o, 0, 0, 0);
-            if (qok) {
-                bf16x4 ob;
+            bf16x4 ob;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)o[r];
-                *reinterpret_cast<bf16x4*>(a.dq + ((size_t)b * a.Sq + q) * a.lddq + h * DH + 16 * dt + 4 * g) = ob;
-            }
+            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)o[r];
+            if (qok) *reinterpret_cast<bf16x4*>(a.dq + ((size_t)b * a.Sq + q) * a.lddq + h * DH + 16 * dt + 4 * g) = ob;
+            if (want_cs) slab_colsum(&cs_part[0][w][16 * dt + 4 * g], ob, qok, lane);
         }
     }
     __syncthreads();
@@ -228,12 +245,24 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
             ov = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Gs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), pf, ov, 0, 0, 0);
             ok = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Qs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), sf, ok, 0, 0, 0);
         }
-        if (kok) {
-            bf16x4 bv, bk;
+        bf16x4 bv, bk;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { bv[r] = (bf16_t)ov[r]; bk[r] = (bf16_t)ok[r]; }
+        for (int r = 0; r < 4; ++r) { bv[r] = (bf16_t)ov[r]; bk[r] = (bf16_t)ok[r]; }
+        if (kok) {
             *reinterpret_cast<bf16x4*>(a.dv + ((size_t)b * a.Skv + kv) * a.lddv + h * DH + 16 * dt + 4 * g) = bv;
             *reinterpret_cast<bf16x4*>(a.dk + ((size_t)b * a.Skv + kv) * a.lddk + h * DH + 16 * dt + 4 * g) = bk;
+        }
+        if (want_cs) {
+            slab_colsum(&cs_part[1][w][16 * dt + 4 * g], bk, kok, lane);
+            slab_colsum(&cs_part[2][w][16 * dt + 4 * g], bv, kok, lane);
+        }
+    }
+    if (want_cs) {
+        __syncthreads();
+        for (int c = tid; c < 3 * DH; c += 256) {
+            const int which = c / DH, col = c % DH;
+            float* dst = which == 0 ? a.dq_cs : which == 1 ? a.dk_cs : a.dv_cs;
+            if (dst) atomicAdd(dst + h * DH + col, cs_part[which][0][col] + cs_part[which][1][col] + cs_part[which][2][col] + cs_part[which][3][col]);
         }
     }
 }
@@ -254,6 +283,7 @@ bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
     a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)d->Dh);
     a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     a.seed = d->drop_seed; a.stream = d->drop_stream;
+    a.dq_cs = bwd ? d->dq_colsum : nullptr; a.dk_cs = bwd ? d->dk_colsum : nullptr; a.dv_cs = bwd ? d->dv_colsum : nullptr;
     return true;
 }
 

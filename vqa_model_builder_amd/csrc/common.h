@@ -33,10 +33,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Gauss error function pieces for the exact ("erf") GELU.  Abramowitz-Stegun 7.1.26: erf(z) = 1 - poly(t) exp(-z^2),
+// t = 1 / (1 + 0.3275911 z), |error| <= 1.5e-7 -- three orders below the bf16 rounding of every value these feed, and a
+// third of the instructions of libm's erff (one v_exp_f32, one v_rcp_f32, six FMAs).  The SAME exp(-x^2/2) is the Gaussian
+// density the derivative needs, so backward costs no second exponential.
+struct GeluParts { float cdf, e; };      // cdf = Phi(x);  e = exp(-x*x/2)
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+    const float ax = fabsf(x), z = ax * 0.70710678118654752440f;
+    const float e = __expf(-z * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_erfc = 0.5f * poly * e;                    // 0.5 * (1 - erf(z))
+    return {x >= 0.f ? 1.0f - half_erfc : half_erfc, e};
+}
+
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
-        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ACT_GELU_ERF: return x * gelu_parts(x).cdf;
+        case ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
         case ACT_RELU: return x > 0.f ? x : 0.f;
         default: return x;
     }
@@ -45,12 +59,11 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
 __device__ __forceinline__ float act_bwd(float x, int act) {
     switch (act) {
         case ACT_GELU_ERF: {
-            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-            return cdf + x * pdf;
+            const GeluParts g = gelu_parts(x);
+            return g.cdf + x * 0.39894228040143267794f * g.e;
         }
         case ACT_QUICK_GELU: {
-            const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+            const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
             return s * (1.0f + 1.702f * x * (1.0f - s));
         }
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
@@ -84,9 +97,26 @@ __device__ __forceinline__ uint64_t resolve_seed(uint64_t s) {
     }
     return s;
 }
-// keep-scale for inverted dropout: 0 or 1/(1-p)
+// Dropout keep-scale (inverted dropout: 0 or 1/(1-p)).  One 64-bit hash serves FOUR consecutive elements -- 16 bits
+// each (p is resolved to 1/65536) -- because the hash, not the compare, is the cost (two 64-bit multiplies): the
+// epilogues that own aligned groups of four call dropout_scale4; dropout_scale is the per-element form of the same map.
+__device__ __forceinline__ uint64_t rng_u64(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)stream << 40);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t stream, uint64_t idx, float p, float inv_keep) {
-    return rng_uniform(seed, stream, idx) >= p ? inv_keep : 0.f;
+    const uint32_t u = (uint32_t)(rng_u64(seed, stream, idx >> 2) >> (16 * (idx & 3))) & 0xFFFFu;
+    return (float)u * (1.0f / 65536.0f) >= p ? inv_keep : 0.f;
+}
+// idx4: index of the first of four consecutive elements, a multiple of 4
+__device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint32_t stream, uint64_t idx4, float p, float inv_keep) {
+    const uint64_t h = rng_u64(seed, stream, idx4 >> 2);
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (float)((uint32_t)(h >> (16 * j)) & 0xFFFFu) * (1.0f / 65536.0f) >= p ? inv_keep : 0.f;
+    return r;
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

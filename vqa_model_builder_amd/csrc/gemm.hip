@@ -145,15 +145,13 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int 
 // (2) Inside that range tiles are walked in GROUPS of group_m tile-rows, tile-row fastest: the ~160 workgroups an XCD
 // holds at once then cover a group_m x ~10 patch of the output, i.e. they share group_m A-panels and ~10 B-panels that
 // fit the L2 together, instead of one A-panel and EVERY B-panel (which thrashes it and sends each tile to the MALL).
+__device__ __forceinline__ int xcd_remap(int t, int ntiles) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective
+}
 template <int BM, int BN>
-__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+__device__ __forceinline__ void tile_from_linear(const GemmArgs& p, int t, int& tm, int& tn) {
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    int t = blockIdx.x;
-    {
-        const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
-    }
     const int gm = p.group_m;
     if (gm <= 1) { tm = t / tiles_n; tn = t % tiles_n; return; }
     const int per_group = gm * tiles_n;
@@ -161,6 +159,11 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn)
     const int rows = min(gm, tiles_m - g * gm);
     tm = g * gm + r % rows;
     tn = r / rows;
+}
+template <int BM, int BN>
+__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+    const int ntiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    tile_from_linear<BM, BN>(p, xcd_remap(blockIdx.x, ntiles), tm, tn);
 }
 
 // Epilogue.  The MFMA leaves lane (r = lane&15, g = lane>>4) with C[16i + r][16j + 4g .. +3]: written straight out, every
@@ -243,11 +246,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
             }
-            if (p.drop_p > 0.f) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] *= dropout_scale(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n + r, p.drop_p, p.drop_inv_keep);
-            }
+            if (p.drop_p > 0.f) v *= dropout_scale4(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
             cs += v;                                      // column sums of the stored values BEFORE the residual (bias gradient)
             if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
             if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
@@ -465,9 +464,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // WM_ x WN_ waves, each a (BM/WM_) x (BN/WN_) wave tile; BKT = 32 or 64 elements of k per ring stage.
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p_in) {
-    GemmArgs p = p_in;
-    if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
+__device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_linear) {
     constexpr int NW = WM_ * WN_;
     constexpr int WTM = BM / WM_, WTN = BN / WN_, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     int tm, tn;
-    tile_coords<BM, BN>(p, tm, tn);
+    tile_from_linear<BM, BN>(p, tile_linear, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -565,6 +562,35 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
         for (int i = 0; i < 32; ++i) p.trace[(size_t)blockIdx.x * 32 + i] = tr[i];
     }
 #endif
+}
+
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p_in) {
+    GemmArgs p = p_in;
+    if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
+    const int ntiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, xcd_remap(blockIdx.x, ntiles));
+}
+
+// GROUPED launch: up to MAX_GROUP independent fp32-output GEMMs of one operand layout in ONE grid (the weight-gradient GEMMs
+// of a backward pass: nothing waits for them, so they are queued and issued together).  One launch pays one cold start and
+// one tail for all of them, and thousands of equal-cost tiles balance over the CUs where a single 768 x 768 output has 144.
+constexpr int MAX_GROUP = 32;
+struct GroupItem { const bf16_t* a; const bf16_t* b; float* c; int M, N, K, lda, ldb, ldc; };
+struct GroupArgs { int n; int group_m; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
+
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
+    const int t = xcd_remap(blockIdx.x, g.tile_end[g.n - 1]);
+    int i = 0;
+    while (i + 1 < g.n && t >= g.tile_end[i]) ++i;
+    const GroupItem& it = g.it[i];
+    GemmArgs p{};
+    p.a = it.a; p.b = it.b; p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb;
+    p.c_f32 = it.c; p.ldc_f32 = it.ldc;
+    p.alpha = 1.f; p.drop_inv_keep = 1.f; p.group_m = g.group_m;
+    p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
+    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
 }
 
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
@@ -722,5 +748,47 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         case 4: return launch_cfg<128, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
         default: return launch_cfg<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
     }
+}
+template <int ST, bool AK, bool BKC>
+static int launch_grouped(const GroupArgs& g, hipStream_t st) {
+    constexpr int LDS = ST * (64 + 64) * 64 * 2;
+    auto kern = gemm_v1_grouped_kernel<64, 64, 2, 2, 64, ST, AK, BKC>;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.tile_end[g.n - 1]), dim3(256), LDS, st, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t stream_) {
+    if (!items || n <= 0 || n > MAX_GROUP) return VQA_ERR_ARG;
+    GroupArgs g{};
+    g.n = n; g.group_m = g_group_m;
+    long tiles = 0, kmin = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+        const VqaGemmGroupItem& d = items[i];
+        if (!d.a || !d.b || !d.c_f32 || d.M <= 0 || d.N <= 0 || d.K <= 0) return VQA_ERR_ARG;
+        if (d.lda % 8 || d.ldb % 8 || d.N % 4 || d.ldc % 4) return VQA_ERR_ARG;
+        if (a_kc ? (d.K % 8) : (d.M % 8)) return VQA_ERR_ARG;
+        if (b_kc ? (d.K % 8) : (d.N % 8)) return VQA_ERR_ARG;
+        if (((uintptr_t)d.a | (uintptr_t)d.b | (uintptr_t)d.c_f32) & 15) return VQA_ERR_ARG;
+        tiles += (long)ceil_div(d.M, 64) * ceil_div(d.N, 64);
+        if (tiles > 0x3fffffff) return VQA_ERR_ARG;
+        g.tile_end[i] = (int)tiles;
+        g.it[i] = GroupItem{(const bf16_t*)d.a, (const bf16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc};
+        kmin = d.K < kmin ? d.K : kmin;
+    }
+    // ring depth as for single launches: the third stage pays when k is long and the grid is under two workgroups per CU
+    const bool deep = kmin >= 2048 && tiles < 512;
+    hipStream_t st = (hipStream_t)stream_;
+#define VQA_G(AK, BKC) (deep ? launch_grouped<3, AK, BKC>(g, st) : launch_grouped<2, AK, BKC>(g, st))
+    if (a_kc && b_kc) return VQA_G(true, true);
+    if (a_kc && !b_kc) return VQA_G(true, false);
+    if (!a_kc && !b_kc) return VQA_G(false, false);
+    return VQA_G(false, true);
+#undef VQA_G
 }
 #endif  // VQA_GEMM_LAB

@@ -53,10 +53,8 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
                 const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c];
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-                    if (drop_p > 0.f) o[j] *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
-                }
+                for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+                if (drop_p > 0.f) o *= dropout_scale4(seed, stream, (uint64_t)row * cols + 4 * c, drop_p, inv_keep);
                 if (y) reinterpret_cast<f32x4*>(y + (size_t)row * cols)[c] = o;
                 if (yb) { bf16x4 ob; for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j]; reinterpret_cast<bf16x4*>(yb + (size_t)row * cols)[c] = ob; }
             }
@@ -71,7 +69,8 @@ template <int NV>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx, bf16_t* __restrict__ dxb,
-    float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode, int want_colsum) {
+    float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode, int want_colsum,
+    float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta, float* __restrict__ acc_colsum) {
     if (drop_p > 0.f) seed = resolve_seed(seed);
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [WAVES][3][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,10 +92,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
             xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; gy[i] = xh[i];
             if (c < c4) {
                 f32x4 d = reinterpret_cast<const f32x4*>(dy + (size_t)row * cols)[c];
-                if (drop_mode == 2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) d[j] *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
-                }
+                if (drop_mode == 2) d *= dropout_scale4(seed, stream, (uint64_t)row * cols + 4 * c, drop_p, inv_keep);
                 const f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[c];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -122,10 +118,11 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
                 if (dx) reinterpret_cast<f32x4*>(dx + (size_t)row * cols)[c] = o;
                 if (dxb || want_colsum) {
                     bf16x4 ob;
+                    f32x4 ks = {1.f, 1.f, 1.f, 1.f};
+                    if (drop_mode == 1) ks = dropout_scale4(seed, stream, (uint64_t)row * cols + 4 * c, drop_p, inv_keep);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float t = o[j];
-                        if (drop_mode == 1) t *= dropout_scale(seed, stream, (uint64_t)row * cols + 4 * c + j, drop_p, inv_keep);
+                        const float t = o[j] * ks[j];
                         ob[j] = (bf16_t)t;
                         cs[i][j] += t;                 // column sum of the (masked) gradient = bias gradient of the producer Linear
                     }
@@ -134,7 +131,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
             }
         }
     }
-    if (!ws) return;
+    if (!ws && !acc_dgamma && !acc_dbeta && !acc_colsum) return;
     f32x4* l4 = reinterpret_cast<f32x4*>(lds);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -146,9 +143,20 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
         f32x4 a = l4[c], b = l4[c4 + c], d = l4[2 * c4 + c];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { a += l4[(w * 3 + 0) * c4 + c]; b += l4[(w * 3 + 1) * c4 + c]; d += l4[(w * 3 + 2) * c4 + c]; }
-        reinterpret_cast<f32x4*>(ws + (size_t)blockIdx.x * cols)[c] = a;
-        reinterpret_cast<f32x4*>(ws + (size_t)(gridDim.x + blockIdx.x) * cols)[c] = b;
-        if (want_colsum) reinterpret_cast<f32x4*>(ws + (size_t)(2 * gridDim.x + blockIdx.x) * cols)[c] = d;
+        if (ws) {
+            reinterpret_cast<f32x4*>(ws + (size_t)blockIdx.x * cols)[c] = a;
+            reinterpret_cast<f32x4*>(ws + (size_t)(gridDim.x + blockIdx.x) * cols)[c] = b;
+            if (want_colsum) reinterpret_cast<f32x4*>(ws + (size_t)(2 * gridDim.x + blockIdx.x) * cols)[c] = d;
+        } else {
+            // accumulate mode: the block's partial sums go straight into the (pre-zeroed) outputs -- no workspace round trip
+            // and no second launch (the reduce kernel cost as much as the backward itself on the path's 2048 x 768 rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (acc_dgamma) atomicAdd(acc_dgamma + 4 * c + j, a[j]);
+                if (acc_dbeta) atomicAdd(acc_dbeta + 4 * c + j, b[j]);
+                if (acc_colsum) atomicAdd(acc_colsum + 4 * c + j, d[j]);
+            }
+        }
     }
 }
 
@@ -208,15 +216,19 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
                       float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s) {
     if (drop_p <= 0.f) drop_mode = 0;
     if (!dy || !x || !mean || !rstd || !gamma || rows <= 0 || cols <= 0 || cols % 4 || cols > 4096) return VQA_ERR_ARG;
-    if ((dgamma || dbeta || dx_colsum) && !ws) return VQA_ERR_ARG;
+    // ws == NULL with reduction outputs requested = ACCUMULATE mode: dgamma / dbeta / dx_colsum += (fp32 atomics), the caller
+    // guarantees they are initialised (the gradient arena is zero-filled once per backward)
+    const bool reduce_out = dgamma || dbeta || dx_colsum;
+    const bool accumulate = reduce_out && !ws;
     const int grid = min(ceil_div(rows, WAVES), BWD_BLOCKS);
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    float* wsp = (dgamma || dbeta || dx_colsum) ? ws : nullptr;
-    const size_t lds_bytes = wsp ? (size_t)WAVES * 3 * cols * 4 : 0;
+    float* wsp = (reduce_out && !accumulate) ? ws : nullptr;
+    float* ag = accumulate ? dgamma : nullptr; float* ab = accumulate ? dbeta : nullptr; float* ac = accumulate ? dx_colsum : nullptr;
+    const size_t lds_bytes = reduce_out ? (size_t)WAVES * 3 * cols * 4 : 0;
     if (lds_bytes > 160 * 1024 - 256) return VQA_ERR_ARG;            // affine/colsum partials need 48*cols bytes of LDS: cols <= 3328
     const int nv = nv_for(cols);
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(WAVES * 64), lds_bytes, (hipStream_t)s, dy, x, mean, rstd, \
-                                      gamma, dres, dx_f32, (bf16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode, dx_colsum ? 1 : 0)
+                                      gamma, dres, dx_f32, (bf16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode, dx_colsum ? 1 : 0, ag, ab, ac)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
     else if (nv <= 8) {
         static bool attr8 = false;       // 8 float4/lane: 96 KiB of LDS for the three-way cross-wave combine

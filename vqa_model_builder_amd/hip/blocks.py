@@ -55,23 +55,38 @@ def new_seed() -> int:
 
 
 class GradArena:
-    """One flat, zero-filled fp32 buffer per block and backward pass holding every parameter gradient of the block
-    (packed where the weights are packed).  One fill kernel replaces the per-GEMM split-K memsets and lets the GEMM /
-    LayerNorm epilogues accumulate bias gradients in place; the block's gradients are contiguous for the DP exchange."""
+    """One flat fp32 buffer per block and backward pass holding every parameter gradient of the block (packed where the
+    weights are packed); the block's gradients are contiguous for the DP exchange.  Two regions:
+      * ACCUMULATED slots first (biases, LayerNorm affine, embedding tables, cls/pos): zero-filled by ONE fill per backward,
+        then added to by GEMM / LayerNorm / attention epilogues (fp32 atomics) and the embedding scatter;
+      * OVERWRITTEN slots behind them (every ``*_w`` Linear weight: each is written whole by its weight-gradient GEMM), which
+        are left uninitialised -- three quarters of the arena's bytes need no fill."""
 
     def __init__(self, params):
         self.slots, self.total = {}, 0
+        shapes = {}
         for key, p in params.items():
             ps = p if isinstance(p, (list, tuple)) else [p]
-            shape = (sum(q.shape[0] for q in ps),) + tuple(ps[0].shape[1:])
+            shapes[key] = (sum(q.shape[0] for q in ps),) + tuple(ps[0].shape[1:])
+        order = [k for k in shapes if not self.overwritten(k)] + [k for k in shapes if self.overwritten(k)]
+        self.zero_total = 0
+        for key in order:
+            shape = shapes[key]
             n = 1
             for d in shape:
                 n *= d
             self.slots[key] = (self.total, n, shape)
             self.total += (n + 3) // 4 * 4                      # 16-byte aligned slots
+            if not self.overwritten(key):
+                self.zero_total = self.total
+
+    @staticmethod
+    def overwritten(key):
+        return key.endswith('_w')
 
     def alloc(self, device):
-        flat = torch.zeros(self.total, dtype=F32, device=device)
+        flat = torch.empty(self.total, dtype=F32, device=device)
+        flat[:self.zero_total].zero_()
         return flat, {k: flat[o:o + n].view(shape) for k, (o, n, shape) in self.slots.items()}
 
 
@@ -126,20 +141,21 @@ class ClipRunner:
         for l in reversed(range(self.L)):
             k = f'l{l}.'
             x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g = saved['layers'][l]
-            K.linear_dw(dxb, g, M, D, I, out=G[k + 'fc2_w'], prezeroed=True)
+            K.linear_dw(dxb, g, M, D, I, out=G[k + 'fc2_w'], prezeroed=False)
             _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU, colsum=G[k + 'fc1_b'])
-            K.linear_dw(da, h2, M, I, D, out=G[k + 'fc1_w'], prezeroed=True)
+            K.linear_dw(da, h2, M, I, D, out=G[k + 'fc1_w'], prezeroed=False)
             dh2, _ = K.linear_dx(da, W.s(k + 'fc1_w'), M, I, D, want_f32=True)
             dx1, dx1b, _, _ = K.layernorm_bwd(dh2, x1, m2, r2, W.p(k + 'ln2.w'), M, D, dres=dx, want_bf16=True,
                                               dgamma=G[k + 'ln2.w'], dbeta=G[k + 'ln2.b'], dx_colsum=G[k + 'out_b'])
-            K.linear_dw(dx1b, ctx, M, D, D, out=G[k + 'out_w'], prezeroed=True)
+            K.linear_dw(dx1b, ctx, M, D, D, out=G[k + 'out_w'], prezeroed=False)
             _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dx.device)
+            qb = G[k + 'qkv_b']
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, T, T, D // H,
-                            dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D)
-            K.linear_dw(dqkv, h1, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=True)
+                            dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D,
+                            dq_colsum=qb[:D], dk_colsum=qb[D:2 * D], dv_colsum=qb[2 * D:])      # qkv bias gradient, fused
+            K.linear_dw(dqkv, h1, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=False)
             dh1, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True)
-            K.colsum_bf16(dqkv, M, 3 * D, out=G[k + 'qkv_b'])
             nxt = G[f'l{l - 1}.fc2_b'] if l > 0 else None                  # dx is the fc2 output gradient of the layer below
             dx, dxb, _, _ = K.layernorm_bwd(dh1, x, m1, r1, W.p(k + 'ln1.w'), M, D, dres=dx1, want_bf16=True,
                                             dgamma=G[k + 'ln1.w'], dbeta=G[k + 'ln1.b'], dx_colsum=nxt)
@@ -147,7 +163,7 @@ class ClipRunner:
                                       dgamma=G['pre_ln.w'], dbeta=G['pre_ln.b'])
         dE = K.clip_assemble_bwd(du, B, P, D, G['cls'], G['pos'])
         Kp = saved['xp'].shape[1]
-        K.linear_dw(dE, saved['xp'], B * P, D, Kp, out=G['patch_w'].view(D, Kp), prezeroed=True)
+        K.linear_dw(dE, saved['xp'], B * P, D, Kp, out=G['patch_w'].view(D, Kp), prezeroed=False)
         K.wgrad_join()
         return G
 
@@ -203,21 +219,22 @@ class RobertaRunner:
             # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g));  bias grad of `dense` = colsum of the masked ds2
             ds2, ds2b, _, _ = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 2), drop_mode=1,
                                               dgamma=G[k + 'o_ln.w'], dbeta=G[k + 'o_ln.b'], dx_colsum=G[k + 'o_b'])
-            K.linear_dw(ds2b, g, M, D, I, out=G[k + 'o_w'], prezeroed=True)
+            K.linear_dw(ds2b, g, M, D, I, out=G[k + 'o_w'], prezeroed=False)
             _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU, colsum=G[k + 'i_b'])
-            K.linear_dw(da, x1b, M, I, D, out=G[k + 'i_w'], prezeroed=True)
+            K.linear_dw(da, x1b, M, I, D, out=G[k + 'i_w'], prezeroed=False)
             dx1, _ = K.linear_dx(da, W.s(k + 'i_w'), M, I, D, want_f32=True, residual=ds2)
             # attention-output LayerNorm:  x1 = LN(s1),  s1 = x + drop(dense(ctx))
             ds1, ds1b, _, _ = K.layernorm_bwd(dx1, s1, m1, r1, W.p(k + 'ao_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 1), drop_mode=1,
                                               dgamma=G[k + 'ao_ln.w'], dbeta=G[k + 'ao_ln.b'], dx_colsum=G[k + 'ao_b'])
-            K.linear_dw(ds1b, ctx, M, D, D, out=G[k + 'ao_w'], prezeroed=True)
+            K.linear_dw(ds1b, ctx, M, D, D, out=G[k + 'ao_w'], prezeroed=False)
             _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+            qb = G[k + 'qkv_b']
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, S, S, D // H,
-                            dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, kpm, Drop(pa, seed, st))
-            K.linear_dw(dqkv, xb, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=True)
+                            dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, kpm, Drop(pa, seed, st),
+                            dq_colsum=qb[:D], dk_colsum=qb[D:2 * D], dv_colsum=qb[2 * D:])      # qkv bias gradient, fused
+            K.linear_dw(dqkv, xb, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=False)
             dx, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True, residual=ds1)
-            K.colsum_bf16(dqkv, M, 3 * D, out=G[k + 'qkv_b'])
         du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
                                       drop=Drop(pd, seed, 1), drop_mode=2, dgamma=G['emb_ln.w'], dbeta=G['emb_ln.b'])
         K.roberta_embed_bwd(du, saved['ids'], saved['pos_ids'], G['word'], G['pos'], G['type'], B, S, D, self.pad)
@@ -277,27 +294,26 @@ class CrossModalAttentionRunner:
         _, G = self.arena.alloc(dev)
         ds3, ds3b, _, _ = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 6), drop_mode=1,
                                           dgamma=G['n3.w'], dbeta=G['n3.b'], dx_colsum=G['ffn3_b'])
-        K.linear_dw(ds3b, S['g'], M, D, I, out=G['ffn3_w'], prezeroed=True)
+        K.linear_dw(ds3b, S['g'], M, D, I, out=G['ffn3_w'], prezeroed=False)
         _, da = K.linear_dx(ds3b, W.s('ffn3_w'), M, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5),
                             colsum=G['ffn0_b'])
-        K.linear_dw(da, S['x2b'], M, I, D, out=G['ffn0_w'], prezeroed=True)
+        K.linear_dw(da, S['x2b'], M, I, D, out=G['ffn0_w'], prezeroed=False)
         dx2, _ = K.linear_dx(da, W.s('ffn0_w'), M, I, D, want_f32=True, residual=ds3)
         # --- cross attention
         ds2, ds2b, _, _ = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 4), drop_mode=1,
                                           dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'])
-        K.linear_dw(ds2b, S['ctx2'], M, D, D, out=G['ca_out_w'], prezeroed=True)
+        K.linear_dw(ds2b, S['ctx2'], M, D, D, out=G['ca_out_w'], prezeroed=False)
         _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
         dq2 = torch.empty((M, D), dtype=BF16, device=dev)
         dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
         kv2 = S['kv2']
         K.attention_bwd(S['q2'], kv2[:, :D], kv2[:, D:], dctx2, D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, dq2, dkv2[:, :D], dkv2[:, D:],
-                        D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3))
+                        D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3),
+                        dq_colsum=G['ca_in_b'][:D], dk_colsum=G['ca_in_b'][D:2 * D], dv_colsum=G['ca_in_b'][2 * D:])
         w_in = W.s('ca_in_w')
-        K.linear_dw(dq2, S['x1b'], M, D, D, out=G['ca_in_w'][:D], prezeroed=True)
+        K.linear_dw(dq2, S['x1b'], M, D, D, out=G['ca_in_w'][:D], prezeroed=False)
         dx1, _ = K.linear_dx(dq2, w_in[:D], M, D, D, want_f32=True, residual=ds2)
-        K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=G['ca_in_w'][D:], prezeroed=True)
-        K.colsum_bf16(dq2, M, D, out=G['ca_in_b'][:D])
-        K.colsum_bf16(dkv2, Mv, 2 * D, out=G['ca_in_b'][D:])
+        K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=G['ca_in_w'][D:], prezeroed=False)
         dkv = None
         if need_dkv:
             dkv, _ = K.linear_dx(dkv2, w_in[D:], Mv, 2 * D, D, want_f32=True)
@@ -305,14 +321,14 @@ class CrossModalAttentionRunner:
         # --- self attention
         ds1, ds1b, _, _ = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 2), drop_mode=1,
                                           dgamma=G['n1.w'], dbeta=G['n1.b'], dx_colsum=G['sa_out_b'])
-        K.linear_dw(ds1b, S['ctx'], M, D, D, out=G['sa_out_w'], prezeroed=True)
+        K.linear_dw(ds1b, S['ctx'], M, D, D, out=G['sa_out_w'], prezeroed=False)
         _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
         qkv = S['qkv']
         dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
         K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh,
-                        dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, S['qm'], Drop(pd, seed, 1))
-        K.linear_dw(dqkv, S['xb'], M, 3 * D, D, out=G['sa_in_w'], prezeroed=True)
+                        dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, S['qm'], Drop(pd, seed, 1),
+                        dq_colsum=G['sa_in_b'][:D], dk_colsum=G['sa_in_b'][D:2 * D], dv_colsum=G['sa_in_b'][2 * D:])
+        K.linear_dw(dqkv, S['xb'], M, 3 * D, D, out=G['sa_in_w'], prezeroed=False)
         dx, _ = K.linear_dx(dqkv, W.s('sa_in_w'), M, 3 * D, D, want_f32=True, residual=ds1)
-        K.colsum_bf16(dqkv, M, 3 * D, out=G['sa_in_b'])
         K.wgrad_join()
         return G, dx.view(B, Sq, D), dkv

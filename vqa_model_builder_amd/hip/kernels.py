@@ -106,29 +106,74 @@ def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, resi
     return of, ob
 
 
-# ---- weight-gradient side stream ---------------------------------------------------------------------------------
-# Nothing in a backward pass waits for a weight gradient (only the optimiser does), while the dX chain is a string of
-# short dependent launches that each leave CUs idle (cold start, C-tile stores).  With WGRAD_SIDE_STREAM on, every
-# linear_dw goes to a side HIP stream that waits on an event recorded after its operands' producers; the block runner joins
-# it at the end of its backward.  Worth it when launches are free (captured into a HIP graph: graph.GraphedTrainStep turns
-# it on); in eager mode the extra event traffic costs host time.  Operands are kept alive until the join, so the caching
-# allocator never hands their memory to the main stream while the side stream still reads it.
+# ---- weight-gradient GEMMs: queued, issued grouped ------------------------------------------------------------------
+# Nothing in a backward pass waits for a weight gradient (only the optimiser does).  linear_dw therefore only QUEUES its GEMM;
+# wgrad_flush() issues everything queued as grouped launches (vqa_gemm_bf16_grouped: up to 32 GEMMs per grid) and the block
+# runner calls it once, at the end of its backward.  One launch then pays one cold start and one tail for a whole encoder's
+# weight gradients and its tens of thousands of equal tiles fill every CU, where a lone 768 x 768 output has 144 tiles.
+# Operands are kept alive until the flush.  WGRAD_SIDE_STREAM additionally moves the grouped launches to a side HIP stream
+# (one cross-stream edge per flush); measured no gain beside the parallel encoder branches, so it is off by default.
+WGRAD_GROUPED = True
 WGRAD_SIDE_STREAM = False
-_wgrad = {}          # main cuda_stream handle -> [side torch.cuda.Stream, keep-alive list]
+WGRAD_GROUP_MAX = 32
+_wgrad = {}          # main cuda_stream handle -> [side torch.cuda.Stream | None, keep-alive list, pending GEMM argument tuples]
+_group_items = None
 
 
 def _wgrad_slot():
     cur = torch.cuda.current_stream()
     slot = _wgrad.get(cur.cuda_stream)
     if slot is None:
-        slot = _wgrad[cur.cuda_stream] = [torch.cuda.Stream(), []]
+        slot = _wgrad[cur.cuda_stream] = [None, [], []]
     return cur, slot
 
 
-def wgrad_join():
-    """Makes the current stream wait for the weight-gradient GEMMs its side stream still runs (end of a block backward)."""
+def _launch_group(pending):
+    global _group_items
+    if _group_items is None:
+        _group_items = (_l.VqaGemmGroupItem * WGRAD_GROUP_MAX)()
+    for i0 in range(0, len(pending), WGRAD_GROUP_MAX):
+        chunk = pending[i0:i0 + WGRAD_GROUP_MAX]
+        for it, a in zip(_group_items, chunk):
+            dy, x, M, N, Kd, ldy, ldx, out, _ = a
+            # dW[N,K] = dy[M,N]^T x[M,K]: GEMM rows = N, columns = K, reduction over the M tokens
+            it.a, it.b, it.c_f32 = _p(dy), _p(x), _p(out)
+            it.M, it.N, it.K, it.lda, it.ldb, it.ldc = N, Kd, M, ldy, ldx, out.stride(0)
+        if GEMM_PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _chk(L().vqa_gemm_bf16_grouped(_group_items, len(chunk), 0, 0, _stream()), 'vqa_gemm_bf16_grouped')
+        if GEMM_PROFILE is not None:
+            e1.record()
+            GEMM_PROFILE.append((sum(2.0 * a[2] * a[3] * a[4] for a in chunk), e0, e1))
+
+
+def wgrad_flush():
+    """Issues the queued weight-gradient GEMMs (grouped), ordered after everything the current stream was given so far."""
     if not _wgrad:
         return
+    cur = torch.cuda.current_stream()
+    slot = _wgrad.get(cur.cuda_stream)
+    if slot is None or not slot[2]:
+        return
+    if WGRAD_SIDE_STREAM:
+        if slot[0] is None:
+            slot[0] = torch.cuda.Stream()
+        slot[0].wait_stream(cur)
+        with torch.cuda.stream(slot[0]):
+            _launch_group(slot[2])
+        slot[1].extend(t for a in slot[2] for t in (a[0], a[1], a[7]))
+    else:
+        _launch_group(slot[2])
+    slot[2].clear()
+
+
+def wgrad_join():
+    """End of a block backward: every queued weight-gradient GEMM is issued and ordered before what the current stream does
+    next (the gradients are about to be handed to autograd)."""
+    if not _wgrad:
+        return
+    wgrad_flush()
     cur = torch.cuda.current_stream()
     slot = _wgrad.get(cur.cuda_stream)
     if slot is not None and slot[1]:
@@ -138,17 +183,15 @@ def wgrad_join():
 
 def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
     """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path).  ``prezeroed``: ``out``
-    is known to be zero (gradient arena), so a split-K launch needs no memset."""
+    is known to be zero (gradient arena), so a split-K launch needs no memset.  With WGRAD_GROUPED (default) and a
+    caller-provided ``out`` the GEMM is only queued: the caller must end its backward with wgrad_join()."""
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=dy_bf16.device)
-        prezeroed = False
-    if WGRAD_SIDE_STREAM and GEMM_PROFILE is None:
-        cur, slot = _wgrad_slot()
-        side = slot[0]
-        side.wait_stream(cur)                      # operands (and the zero-filled arena) are ready at this point of the main stream
-        with torch.cuda.stream(side):
-            gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed)
-        slot[1].extend((dy_bf16, x_bf16, out))
+        gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=False)
+        return out
+    if WGRAD_GROUPED and out.stride(-1) == 1 and M % 8 == 0 and N % 8 == 0 and K % 8 == 0:
+        _, slot = _wgrad_slot()
+        slot[2].append((dy_bf16, x_bf16, M, N, K, ldy or N, ldx or K, out, prezeroed))
         return out
     gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed)
     return out
@@ -214,11 +257,18 @@ def layernorm_fwd(x, gamma, beta, rows, cols, *, add=None, want_f32=True, want_b
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=True, want_bf16=False, want_affine=True,
-                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None, dx_colsum=None):
+                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None, dx_colsum=None, accumulate=False):
+    """``accumulate``: dgamma / dbeta / dx_colsum (all caller-provided, initialised -- slots of a zero-filled GradArena) are
+    ADDED to with fp32 atomics: one launch, no workspace (see include/vqa_hip.h)."""
     dev = dy.device
     dx = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
     dxb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
     ws = None
+    if accumulate:
+        assert dgamma is not None and dbeta is not None
+        _chk(L().vqa_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb), _p(dgamma), _p(dbeta),
+                                   _p(dx_colsum), None, rows, cols, drop.p, drop.seed, drop.stream, drop_mode, _stream()), 'vqa_layernorm_bwd')
+        return dx, dxb, dgamma, dbeta
     if want_affine:
         if dgamma is None:
             dgamma = torch.empty((cols,), dtype=F32, device=dev)
@@ -249,7 +299,8 @@ def attention_fwd(q, k, v, ldq, ldk, ldv, B, H, Sq, Skv, Dh, mask_u8=None, drop:
 
 
 def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, lddq, lddk, lddv, mask_u8=None,
-                  drop: Drop = NO_DROP):
+                  drop: Drop = NO_DROP, dq_colsum=None, dk_colsum=None, dv_colsum=None):
+    """``d*_colsum`` (fp32 [H*Dh], zero on entry -- gradient-arena slots): bias gradients of the Q/K/V projections, fused."""
     d = _ad
     d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), None
     d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, H * Dh
@@ -258,7 +309,9 @@ def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, ld
     d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
     d.d_o, d.ldd_o = _p(d_o), H * Dh
     d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = _p(dq), _p(dk), _p(dv), lddq, lddk, lddv
+    d.dq_colsum, d.dk_colsum, d.dv_colsum = _p(dq_colsum), _p(dk_colsum), _p(dv_colsum)
     _chk(L().vqa_attention_bwd(C.byref(d), _stream()), 'vqa_attention_bwd')
+    d.dq_colsum = d.dk_colsum = d.dv_colsum = None
 
 
 # ---- CLIP / RoBERTa front ends ------------------------------------------------------------------------------------

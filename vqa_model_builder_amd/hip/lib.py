@@ -25,7 +25,11 @@ class VqaAttnDesc(C.Structure):
                 ('B', i32), ('H', i32), ('Sq', i32), ('Skv', i32), ('Dh', i32), ('key_padding_mask', vp),
                 ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32),
                 ('d_o', vp), ('ldd_o', i32), ('dq', vp), ('dk', vp), ('dv', vp),
-                ('lddq', i32), ('lddk', i32), ('lddv', i32)]
+                ('lddq', i32), ('lddk', i32), ('lddv', i32), ('dq_colsum', vp), ('dk_colsum', vp), ('dv_colsum', vp)]
+
+
+class VqaGemmGroupItem(C.Structure):
+    _fields_ = [('a', vp), ('b', vp), ('c_f32', vp), ('M', i32), ('N', i32), ('K', i32), ('lda', i32), ('ldb', i32), ('ldc', i32)]
 
 
 class VqaAdamWDesc(C.Structure):
@@ -73,6 +77,7 @@ SIGNATURES = {
     'vqa_moe_route_weight_grad': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'vqa_randn_f32': (i32, [vp, u64, u64, u32, vp]),
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
+    'vqa_gemm_bf16_grouped': (i32, [vp, i32, i32, i32, vp]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
     'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
