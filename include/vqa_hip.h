@@ -119,6 +119,19 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
                       const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum,
                       float* ws, int rows, int cols, float drop_p, uint64_t drop_seed, uint32_t drop_stream,
                       int drop_mode, vqa_stream_t s);
+/* The same backward with the final reduction of the per-workgroup partials DEFERRED: ws (vqa_layernorm_bwd_ws_floats)
+ * keeps vqa_layernorm_bwd_blocks(rows) partial rows each of dgamma | dbeta | dx_colsum (the last when want_colsum), and
+ * vqa_layernorm_reduce_grouped sums the partials of up to 32 such calls in ONE launch (a block runner issues it once at the
+ * end of its backward instead of one short launch behind every LayerNorm). */
+int vqa_layernorm_bwd_blocks(int rows);
+int vqa_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* dres, float* dx_f32, void* dx_bf16, int want_colsum, float* ws, int rows, int cols,
+                               float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s);
+typedef struct VqaLnReduceItem {
+    const float* ws; int nblocks; int cols;
+    float* dgamma; float* dbeta; float* dx_colsum;      /* each optional, [cols], overwritten */
+} VqaLnReduceItem;
+int vqa_layernorm_reduce_grouped(const VqaLnReduceItem* items, int n, vqa_stream_t s);
 
 /* ---- attention: softmax(Q K^T / sqrt(Dh) + key_padding) V per (batch, head) ------------------------------
  * Replaces HF CLIP/RoBERTa self-attention and nn.MultiheadAttention's core (vqa_model.py:300,304).

@@ -185,6 +185,38 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
     }
 }
 
+// GROUPED form of the reduce: the partials of up to 32 LayerNorm backwards (one encoder's worth) summed by ONE launch at the
+// end of the block's backward instead of one 8-us launch behind each of them.  blockIdx -> (item, 64-column chunk).
+constexpr int MAX_LN_GROUP = 32;
+struct LnReduceItem { const float* ws; float* dgamma; float* dbeta; float* colsum; int nblocks, cols; };
+struct LnReduceGroup { int n; int blk_end[MAX_LN_GROUP]; LnReduceItem it[MAX_LN_GROUP]; };
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_grouped_kernel(const LnReduceGroup g) {
+    __shared__ float red[3][16][64];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.blk_end[i]) ++i;
+    const LnReduceItem& it = g.it[i];
+    const int chunk = blockIdx.x - (i ? g.blk_end[i - 1] : 0);
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = chunk * 64 + lane, cols = it.cols, nblocks = it.nblocks;
+    const float* ws = it.ws;
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (c < cols) {
+        for (int k = rg; k < nblocks; k += 16) {
+            a += ws[(size_t)k * cols + c]; b += ws[(size_t)(nblocks + k) * cols + c];
+            if (it.colsum) d += ws[(size_t)(2 * nblocks + k) * cols + c];
+        }
+    }
+    red[0][rg][lane] = a; red[1][rg][lane] = b; red[2][rg][lane] = d;
+    __syncthreads();
+    if (rg < 3 && c < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[rg][k][lane];
+        float* out = rg == 0 ? it.dgamma : rg == 1 ? it.dbeta : it.colsum;
+        if (out) out[c] = v;
+    }
+}
+
 constexpr int BWD_BLOCKS = 256;
 
 inline int nv_for(int cols) { return ceil_div(cols / 4, 64); }
@@ -210,6 +242,41 @@ int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, cons
 }
 
 size_t vqa_layernorm_bwd_ws_floats(int cols) { return (size_t)3 * BWD_BLOCKS * cols; }
+int vqa_layernorm_bwd_blocks(int rows) { return min(ceil_div(rows, WAVES), BWD_BLOCKS); }
+
+static bool g_ln_defer_reduce = false;     // set around a call by vqa_layernorm_bwd_partials
+
+int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                      float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int cols,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s);
+
+int vqa_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                               float* dx_f32, void* dx_bf16, int want_colsum, float* ws, int rows, int cols,
+                               float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s) {
+    if (!ws) return VQA_ERR_ARG;
+    g_ln_defer_reduce = true;
+    // non-null dummies select what the kernel accumulates; nothing is written through them when the reduce is deferred
+    const int rc = vqa_layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx_f32, dx_bf16, ws, ws, want_colsum ? ws : nullptr, ws, rows, cols,
+                                     drop_p, drop_seed, drop_stream, drop_mode, s);
+    g_ln_defer_reduce = false;
+    return rc;
+}
+
+int vqa_layernorm_reduce_grouped(const VqaLnReduceItem* items, int n, vqa_stream_t s) {
+    if (!items || n <= 0 || n > MAX_LN_GROUP) return VQA_ERR_ARG;
+    LnReduceGroup g{};
+    g.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const VqaLnReduceItem& d = items[i];
+        if (!d.ws || d.nblocks <= 0 || d.cols <= 0) return VQA_ERR_ARG;
+        blocks += ceil_div(d.cols, 64);
+        g.blk_end[i] = blocks;
+        g.it[i] = LnReduceItem{d.ws, d.dgamma, d.dbeta, d.dx_colsum, d.nblocks, d.cols};
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce_grouped_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)s, g);
+    return (int)hipGetLastError();
+}
 
 int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                       float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int cols,
@@ -243,7 +310,7 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 #undef LN_BWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    if (wsp) {
+    if (wsp && !g_ln_defer_reduce) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(cols, 64)), dim3(1024), 0, (hipStream_t)s, ws, grid, cols, dgamma, dbeta, dx_colsum);
         e = hipGetLastError();
     }

@@ -146,7 +146,7 @@ class ClipRunner:
             K.linear_dw(da, h2, M, I, D, out=G[k + 'fc1_w'], prezeroed=False)
             dh2, _ = K.linear_dx(da, W.s(k + 'fc1_w'), M, I, D, want_f32=True)
             dx1, dx1b, _, _ = K.layernorm_bwd(dh2, x1, m2, r2, W.p(k + 'ln2.w'), M, D, dres=dx, want_bf16=True,
-                                              dgamma=G[k + 'ln2.w'], dbeta=G[k + 'ln2.b'], dx_colsum=G[k + 'out_b'])
+                                              dgamma=G[k + 'ln2.w'], dbeta=G[k + 'ln2.b'], dx_colsum=G[k + 'out_b'], defer=True)
             K.linear_dw(dx1b, ctx, M, D, D, out=G[k + 'out_w'], prezeroed=False)
             _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dx.device)
@@ -158,12 +158,13 @@ class ClipRunner:
             dh1, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True)
             nxt = G[f'l{l - 1}.fc2_b'] if l > 0 else None                  # dx is the fc2 output gradient of the layer below
             dx, dxb, _, _ = K.layernorm_bwd(dh1, x, m1, r1, W.p(k + 'ln1.w'), M, D, dres=dx1, want_bf16=True,
-                                            dgamma=G[k + 'ln1.w'], dbeta=G[k + 'ln1.b'], dx_colsum=nxt)
+                                            dgamma=G[k + 'ln1.w'], dbeta=G[k + 'ln1.b'], dx_colsum=nxt, defer=True)
         du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('pre_ln.w'), M, D,
-                                      dgamma=G['pre_ln.w'], dbeta=G['pre_ln.b'])
+                                      dgamma=G['pre_ln.w'], dbeta=G['pre_ln.b'], defer=True)
         dE = K.clip_assemble_bwd(du, B, P, D, G['cls'], G['pos'])
         Kp = saved['xp'].shape[1]
         K.linear_dw(dE, saved['xp'], B * P, D, Kp, out=G['patch_w'].view(D, Kp), prezeroed=False)
+        K.ln_reduce_flush()
         K.wgrad_join()
         return G
 
@@ -218,14 +219,14 @@ class RobertaRunner:
             xb, qkv, ctx, s1, m1, r1, x1b, a, g, s2, m2, r2 = saved['layers'][l]
             # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g));  bias grad of `dense` = colsum of the masked ds2
             ds2, ds2b, _, _ = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 2), drop_mode=1,
-                                              dgamma=G[k + 'o_ln.w'], dbeta=G[k + 'o_ln.b'], dx_colsum=G[k + 'o_b'])
+                                              dgamma=G[k + 'o_ln.w'], dbeta=G[k + 'o_ln.b'], dx_colsum=G[k + 'o_b'], defer=True)
             K.linear_dw(ds2b, g, M, D, I, out=G[k + 'o_w'], prezeroed=False)
             _, da = K.linear_dx(ds2b, W.s(k + 'o_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_GELU, colsum=G[k + 'i_b'])
             K.linear_dw(da, x1b, M, I, D, out=G[k + 'i_w'], prezeroed=False)
             dx1, _ = K.linear_dx(da, W.s(k + 'i_w'), M, I, D, want_f32=True, residual=ds2)
             # attention-output LayerNorm:  x1 = LN(s1),  s1 = x + drop(dense(ctx))
             ds1, ds1b, _, _ = K.layernorm_bwd(dx1, s1, m1, r1, W.p(k + 'ao_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 1), drop_mode=1,
-                                              dgamma=G[k + 'ao_ln.w'], dbeta=G[k + 'ao_ln.b'], dx_colsum=G[k + 'ao_b'])
+                                              dgamma=G[k + 'ao_ln.w'], dbeta=G[k + 'ao_ln.b'], dx_colsum=G[k + 'ao_b'], defer=True)
             K.linear_dw(ds1b, ctx, M, D, D, out=G[k + 'ao_w'], prezeroed=False)
             _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
             dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
@@ -236,8 +237,9 @@ class RobertaRunner:
             K.linear_dw(dqkv, xb, M, 3 * D, D, out=G[k + 'qkv_w'], prezeroed=False)
             dx, _ = K.linear_dx(dqkv, W.s(k + 'qkv_w'), M, 3 * D, D, want_f32=True, residual=ds1)
         du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
-                                      drop=Drop(pd, seed, 1), drop_mode=2, dgamma=G['emb_ln.w'], dbeta=G['emb_ln.b'])
+                                      drop=Drop(pd, seed, 1), drop_mode=2, dgamma=G['emb_ln.w'], dbeta=G['emb_ln.b'], defer=True)
         K.roberta_embed_bwd(du, saved['ids'], saved['pos_ids'], G['word'], G['pos'], G['type'], B, S, D, self.pad)
+        K.ln_reduce_flush()
         K.wgrad_join()
         return G
 
@@ -293,7 +295,7 @@ class CrossModalAttentionRunner:
         dev = dx3.device
         _, G = self.arena.alloc(dev)
         ds3, ds3b, _, _ = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 6), drop_mode=1,
-                                          dgamma=G['n3.w'], dbeta=G['n3.b'], dx_colsum=G['ffn3_b'])
+                                          dgamma=G['n3.w'], dbeta=G['n3.b'], dx_colsum=G['ffn3_b'], defer=True)
         K.linear_dw(ds3b, S['g'], M, D, I, out=G['ffn3_w'], prezeroed=False)
         _, da = K.linear_dx(ds3b, W.s('ffn3_w'), M, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5),
                             colsum=G['ffn0_b'])
@@ -301,7 +303,7 @@ class CrossModalAttentionRunner:
         dx2, _ = K.linear_dx(da, W.s('ffn0_w'), M, I, D, want_f32=True, residual=ds3)
         # --- cross attention
         ds2, ds2b, _, _ = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 4), drop_mode=1,
-                                          dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'])
+                                          dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'], defer=True)
         K.linear_dw(ds2b, S['ctx2'], M, D, D, out=G['ca_out_w'], prezeroed=False)
         _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
         dq2 = torch.empty((M, D), dtype=BF16, device=dev)
@@ -320,7 +322,7 @@ class CrossModalAttentionRunner:
             dkv = dkv.view(B, Skv, D)
         # --- self attention
         ds1, ds1b, _, _ = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), M, D, want_bf16=True, drop=Drop(pd, seed, 2), drop_mode=1,
-                                          dgamma=G['n1.w'], dbeta=G['n1.b'], dx_colsum=G['sa_out_b'])
+                                          dgamma=G['n1.w'], dbeta=G['n1.b'], dx_colsum=G['sa_out_b'], defer=True)
         K.linear_dw(ds1b, S['ctx'], M, D, D, out=G['sa_out_w'], prezeroed=False)
         _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
         qkv = S['qkv']
@@ -330,5 +332,6 @@ class CrossModalAttentionRunner:
                         dq_colsum=G['sa_in_b'][:D], dk_colsum=G['sa_in_b'][D:2 * D], dv_colsum=G['sa_in_b'][2 * D:])
         K.linear_dw(dqkv, S['xb'], M, 3 * D, D, out=G['sa_in_w'], prezeroed=False)
         dx, _ = K.linear_dx(dqkv, W.s('sa_in_w'), M, 3 * D, D, want_f32=True, residual=ds1)
+        K.ln_reduce_flush()
         K.wgrad_join()
         return G, dx.view(B, Sq, D), dkv

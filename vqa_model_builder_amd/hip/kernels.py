@@ -256,14 +256,44 @@ def layernorm_fwd(x, gamma, beta, rows, cols, *, add=None, want_f32=True, want_b
     return y, yb, mean, rstd
 
 
+LN_REDUCE_GROUPED = True
+_ln_pending = {}
+_ln_items = None
+
+
+def ln_reduce_flush():
+    """Sums the partials of every deferred layernorm_bwd of the current stream (grouped launches of up to 32)."""
+    global _ln_items
+    pend = _ln_pending.get(torch.cuda.current_stream().cuda_stream)
+    if not pend:
+        return
+    if _ln_items is None:
+        _ln_items = (_l.VqaLnReduceItem * 32)()
+    for i0 in range(0, len(pend), 32):
+        chunk = pend[i0:i0 + 32]
+        for it, (ws, nb, cols, dg, db, cs) in zip(_ln_items, chunk):
+            it.ws, it.nblocks, it.cols, it.dgamma, it.dbeta, it.dx_colsum = _p(ws), nb, cols, _p(dg), _p(db), _p(cs)
+        _chk(L().vqa_layernorm_reduce_grouped(_ln_items, len(chunk), _stream()), 'vqa_layernorm_reduce_grouped')
+    pend.clear()
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=True, want_bf16=False, want_affine=True,
-                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None, dx_colsum=None, accumulate=False):
+                  drop: Drop = NO_DROP, drop_mode=0, dgamma=None, dbeta=None, dx_colsum=None, accumulate=False, defer=False):
     """``accumulate``: dgamma / dbeta / dx_colsum (all caller-provided, initialised -- slots of a zero-filled GradArena) are
     ADDED to with fp32 atomics: one launch, no workspace (see include/vqa_hip.h)."""
     dev = dy.device
     dx = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
     dxb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
     ws = None
+    if LN_REDUCE_GROUPED and defer and dgamma is not None and dbeta is not None:
+        # partial sums only; ln_reduce_flush() (end of the block's backward) sums the partials of all deferred calls in one launch
+        ws = torch.empty((L().vqa_layernorm_bwd_ws_floats(cols),), dtype=F32, device=dev)
+        _chk(L().vqa_layernorm_bwd_partials(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb),
+                                            1 if dx_colsum is not None else 0, _p(ws), rows, cols, drop.p, drop.seed, drop.stream,
+                                            drop_mode, _stream()), 'vqa_layernorm_bwd_partials')
+        _ln_pending.setdefault(torch.cuda.current_stream().cuda_stream, []).append(
+            (ws, L().vqa_layernorm_bwd_blocks(rows), cols, dgamma, dbeta, dx_colsum))
+        return dx, dxb, dgamma, dbeta
     if accumulate:
         assert dgamma is not None and dbeta is not None
         _chk(L().vqa_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb), _p(dgamma), _p(dbeta),

@@ -32,6 +32,10 @@ class VqaGemmGroupItem(C.Structure):
     _fields_ = [('a', vp), ('b', vp), ('c_f32', vp), ('M', i32), ('N', i32), ('K', i32), ('lda', i32), ('ldb', i32), ('ldc', i32)]
 
 
+class VqaLnReduceItem(C.Structure):
+    _fields_ = [('ws', vp), ('nblocks', i32), ('cols', i32), ('dgamma', vp), ('dbeta', vp), ('dx_colsum', vp)]
+
+
 class VqaAdamWDesc(C.Structure):
     _fields_ = [('param', vp), ('grad', vp), ('exp_avg', vp), ('exp_avg_sq', vp), ('param_bf16', vp), ('n', u64),
                 ('lr', f32), ('beta1', f32), ('beta2', f32), ('eps', f32), ('weight_decay', f32),
@@ -78,6 +82,9 @@ SIGNATURES = {
     'vqa_randn_f32': (i32, [vp, u64, u64, u32, vp]),
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
     'vqa_gemm_bf16_grouped': (i32, [vp, i32, i32, i32, vp]),
+    'vqa_layernorm_bwd_blocks': (i32, [i32]),
+    'vqa_layernorm_bwd_partials': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, u64, u32, i32, vp]),
+    'vqa_layernorm_reduce_grouped': (i32, [vp, i32, vp]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
     'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
