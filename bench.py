@@ -237,8 +237,18 @@ def main():
         tot_flop = sum(f for f, _, _ in prof)
         tot_ms = sum(a.elapsed_time(b) for _, a, b in prof)
         ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel<BM,BN,...> (all MFMA GEMM launches of a step)', 'achieved': round(ach, 2),
-                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process; they were collected with
+        # rocprofv3 on this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) and committed
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'gemm_traffic.json')))
+            if args.workload == 'cfg2_xattn' and args.batch == 32:
+                traffic, traffic_src = tj['hbm_bytes_per_gemm_launch'], 'profiles/r01/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)'
+        except Exception:
+            pass
+        roofline = {'bound': 'mfma', 'kernel': 'gemm_v1_kernel / gemm_v1_grouped_kernel (all MFMA GEMM launches of a step)', 'achieved': round(ach, 2),
+                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_unit': 'B/launch (HBM side)', 'traffic_source': traffic_src,
                     'launches_per_step': len(prof) // 2, 'gemm_ms_per_step': round(tot_ms / 2, 3),
                     'gemm_gflop_per_step': round(tot_flop / 2 / 1e9, 1),
                     'whole_step_tflops': round(GFLOP_PER_SAMPLE[args.workload] * args.batch / (ms * 1e-3) / 1e3, 2)}
