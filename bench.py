@@ -153,10 +153,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    # rehearsal on a one-GPU box: VQA_BENCH_REHEARSE=1 runs all ranks on cuda:0 over gloo (RCCL refuses two ranks per device);
+    # it exercises the multi-process code path of this file, not its performance
+    rehearse = os.environ.get('VQA_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
@@ -175,7 +183,7 @@ def main():
     model = build_model(args.workload, device).train()
     opt = make_optimizer(model, args.torch_optimizer)
     params = [p for p in model.parameters() if p.requires_grad]
-    reducer = GradReducer(params).attach() if world > 1 else None      # overlap: buckets go on the wire during backward
+    reducer = GradReducer(params) if world > 1 else None
     px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
 
     def eager_step():
@@ -192,15 +200,34 @@ def main():
     # Single GPU, no MoE (its dispatch reads expert counts on the host): the whole step -- forward, backward, clip, AdamW --
     # is ONE captured HIP graph with the two encoders as parallel branches; every replay copies a batch into the static
     # input buffers, draws fresh dropout masks (device-side RNG epoch) and advances the optimiser's device-side step count.
-    use_graph = world == 1 and not args.eager and not args.torch_optimizer and WORKLOADS[args.workload][1] == 0
+    # N > 1: forward+backward is one graph, the bucketed RCCL all-reduce is launched eagerly between the replays (collectives
+    # stay outside the capture), the optimiser step is a second graph.  Should the capture fail beside an initialised process
+    # group (the capture decision is all-or-nothing across ranks) every rank falls back to the eager step with the
+    # gradient exchange overlapped into backward by hooks.
+    use_graph = not args.eager and not args.torch_optimizer and WORKLOADS[args.workload][1] == 0
     step = eager_step
+    launch = 'eager'
     if use_graph:
         from vqa_model_builder_amd.graph import GraphedTrainStep
         batch = dict(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
-        graphed = GraphedTrainStep(model, opt, batch, warmup=3)
+        ok = 1
+        try:
+            graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer,
+                                       capture_error_mode='thread_local' if world > 1 else 'global')
+        except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
+            ok = 0
+            print(f'[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); eager step', file=sys.stderr, flush=True)
+        if world > 1:
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            launch = 'hip-graph (2 parallel encoder branches)' + ('; eager RCCL all-reduce between the backward and optimiser graphs' if world > 1 else '')
 
-        def step():
-            return graphed(batch)
+            def step():
+                return graphed(batch)
+    if launch == 'eager' and reducer is not None:
+        reducer.attach()                             # overlap: buckets go on the wire during backward
 
     def fence():
         torch.cuda.synchronize()
@@ -268,7 +295,7 @@ def main():
             'config': {'workload': WORKLOADS[args.workload][2], 'name': args.workload, 'batch_per_gpu': args.batch,
                        'global_batch': args.batch * world, 'image': '3x224x224', 'seq_len': 64,
                        'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
-                       'launch': 'hip-graph (2 parallel encoder branches)' if use_graph else 'eager',
+                       'launch': launch,
                        'final_loss': round(final_loss, 4)},
             'roofline': roofline, 'cpu_baseline': cpu,
         }

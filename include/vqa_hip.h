@@ -66,7 +66,8 @@ typedef struct VqaGemmGroupItem {
     const void* a; const void* b; float* c_f32;
     int M, N, K, lda, ldb, ldc;
 } VqaGemmGroupItem;
-int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);
+int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);   /* a_kc == b_kc */
+void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
 void vqa_set_gemm_group_m(int g);          /* tile-row group of the L2-aware tile order (default 16; <= 1 = row-major) */
 void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */

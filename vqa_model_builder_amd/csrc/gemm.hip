@@ -749,10 +749,10 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         default: return launch_cfg<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
     }
 }
-template <int ST, bool AK, bool BKC>
+template <int BM, int BN, int ST, bool AK, bool BKC>
 static int launch_grouped(const GroupArgs& g, hipStream_t st) {
-    constexpr int LDS = ST * (64 + 64) * 64 * 2;
-    auto kern = gemm_v1_grouped_kernel<64, 64, 2, 2, 64, ST, AK, BKC>;
+    constexpr int LDS = ST * (BM + BN) * 64 * 2;
+    auto kern = gemm_v1_grouped_kernel<BM, BN, 2, 2, 64, ST, AK, BKC>;
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -763,11 +763,12 @@ static int launch_grouped(const GroupArgs& g, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+int g_group_tile = 0;      // 0: heuristic; 1: 64x64; 2: 128x64; 3: 128x128 (diagnostics: vqa_set_gemm_group_tile)
+extern "C" void vqa_set_gemm_group_tile(int t) { g_group_tile = t; }
+
 extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t stream_) {
     if (!items || n <= 0 || n > MAX_GROUP) return VQA_ERR_ARG;
-    GroupArgs g{};
-    g.n = n; g.group_m = g_group_m;
-    long tiles = 0, kmin = 1 << 30;
+    long flops = 0, kmin = 1 << 30, t64 = 0;
     for (int i = 0; i < n; ++i) {
         const VqaGemmGroupItem& d = items[i];
         if (!d.a || !d.b || !d.c_f32 || d.M <= 0 || d.N <= 0 || d.K <= 0) return VQA_ERR_ARG;
@@ -775,20 +776,33 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
         if (a_kc ? (d.K % 8) : (d.M % 8)) return VQA_ERR_ARG;
         if (b_kc ? (d.K % 8) : (d.N % 8)) return VQA_ERR_ARG;
         if (((uintptr_t)d.a | (uintptr_t)d.b | (uintptr_t)d.c_f32) & 15) return VQA_ERR_ARG;
-        tiles += (long)ceil_div(d.M, 64) * ceil_div(d.N, 64);
+        t64 += (long)ceil_div(d.M, 64) * ceil_div(d.N, 64);
+        kmin = d.K < kmin ? d.K : kmin;
+        flops += 2L * d.M * d.N * d.K;
+    }
+    // Tile: with thousands of tiles in the grid the per-workgroup DMA rate no longer decides (occupancy is free), bytes per
+    // FLOP does: 128x128 once there are >= 8 rounds of them over the 256 CUs, else the 64x64 tile of the single launches.
+    int tile = g_group_tile;
+    if (tile == 0) tile = t64 / 4 >= 8 * 256 ? 3 : 1;
+    const int bm = tile == 1 ? 64 : 128, bn = tile == 3 ? 128 : 64;
+    GroupArgs g{};
+    g.n = n; g.group_m = g_group_m;
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const VqaGemmGroupItem& d = items[i];
+        tiles += (long)ceil_div(d.M, bm) * ceil_div(d.N, bn);
         if (tiles > 0x3fffffff) return VQA_ERR_ARG;
         g.tile_end[i] = (int)tiles;
         g.it[i] = GroupItem{(const bf16_t*)d.a, (const bf16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc};
-        kmin = d.K < kmin ? d.K : kmin;
     }
     // ring depth as for single launches: the third stage pays when k is long and the grid is under two workgroups per CU
-    const bool deep = kmin >= 2048 && tiles < 512;
+    const bool deep = tile == 1 && kmin >= 2048 && tiles < 512;
     hipStream_t st = (hipStream_t)stream_;
-#define VQA_G(AK, BKC) (deep ? launch_grouped<3, AK, BKC>(g, st) : launch_grouped<2, AK, BKC>(g, st))
-    if (a_kc && b_kc) return VQA_G(true, true);
-    if (a_kc && !b_kc) return VQA_G(true, false);
+#define VQA_G(AK, BKC) (tile == 3 ? launch_grouped<128, 128, 2, AK, BKC>(g, st) : tile == 2 ? launch_grouped<128, 64, 2, AK, BKC>(g, st) \
+                        : deep ? launch_grouped<64, 64, 3, AK, BKC>(g, st) : launch_grouped<64, 64, 2, AK, BKC>(g, st))
     if (!a_kc && !b_kc) return VQA_G(false, false);
-    return VQA_G(false, true);
+    if (a_kc && b_kc) return VQA_G(true, true);
+    return VQA_ERR_ARG;          // mixed layouts: not instantiated (no caller)
 #undef VQA_G
 }
 #endif  // VQA_GEMM_LAB

@@ -26,7 +26,8 @@ from .hip import blocks as _blocks
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
-                 reducer=None, warmup: int = 3, parallel_towers: bool = True, wgrad_side_stream: bool = False):
+                 reducer=None, warmup: int = 3, parallel_towers: bool = True, wgrad_side_stream: bool = False,
+                 capture_error_mode: str = 'global'):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).  ``loss_of(output)`` picks the
         scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer`` in NON-overlap mode.
         ``parallel_towers``: the vision encoder runs as a parallel branch of the graph (measured on MI355X, cfg2, B=32:
@@ -55,18 +56,22 @@ class GraphedTrainStep:
             self.opt.make_capturable(dev)
         self.g_main = torch.cuda.CUDAGraph()
         self.g_opt = None
+        # capture_error_mode 'thread_local' when other threads may touch the device during the capture (the process group's
+        # watchdog polls events)
         if reducer is None:
-            with torch.cuda.graph(self.g_main):
+            with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode):
                 self.loss = self._fwd_bwd()
                 self.opt.step()
         else:
-            with torch.cuda.graph(self.g_main):
+            with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode):
                 self.loss = self._fwd_bwd()
-            reducer.reduce()                               # fixes p.grad -> bucket views, the addresses the optimiser graph reads
+            # a capture records, it does not run: the gradient buffers hold nothing meaningful yet.  reduce() is called for its
+            # side effects only -- it records where each gradient lives (reduce_static packs from there after every replay)
+            # and re-points p.grad at the bucket slices, the addresses the optimiser graph is captured against.
+            reducer.reduce()
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_main.pool()):
+            with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=capture_error_mode):
                 self.opt.step()
-            self._grads_after_bwd = None
 
     def _fwd_bwd(self):
         from .hip import kernels as K
