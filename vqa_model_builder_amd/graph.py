@@ -27,7 +27,7 @@ from .hip import blocks as _blocks
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True, wgrad_side_stream: bool = False,
-                 capture_error_mode: str = 'global'):
+                 capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).  ``loss_of(output)`` picks the
         scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer`` in NON-overlap mode.
         ``parallel_towers``: the vision encoder runs as a parallel branch of the graph (measured on MI355X, cfg2, B=32:
@@ -41,6 +41,7 @@ class GraphedTrainStep:
         if parallel_towers and hasattr(model, 'encode_visual'):
             model.parallel_towers = True
         self._wgrad_side = wgrad_side_stream
+        self._defer_wgrad = defer_wgrad
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -59,7 +60,7 @@ class GraphedTrainStep:
         # capture_error_mode 'thread_local' when other threads may touch the device during the capture (the process group's
         # watchdog polls events)
         if reducer is None:
-            with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode):
+            with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode, stream=capture_stream):
                 self.loss = self._fwd_bwd()
                 self.opt.step()
         else:
@@ -78,12 +79,14 @@ class GraphedTrainStep:
         _blocks.advance_rng_epoch()
         self.opt.zero_grad(set_to_none=True)
         prev, K.WGRAD_SIDE_STREAM = K.WGRAD_SIDE_STREAM, self._wgrad_side
+        prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
             out = self.model(**self.static)
             loss = self.loss_of(out)
             loss.backward()
+            K.wgrad_flush_all()
         finally:
-            K.WGRAD_SIDE_STREAM = prev
+            K.WGRAD_SIDE_STREAM, K.WGRAD_DEFER_TO_STEP_END = prev, prev_defer
         return loss.detach()
 
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:

@@ -168,10 +168,25 @@ def wgrad_flush():
     slot[2].clear()
 
 
+WGRAD_DEFER_TO_STEP_END = False      # graph mode: block runners leave their queues alone; the step calls wgrad_flush_all()
+
+
+def wgrad_flush_all():
+    """Issues every queued weight-gradient GEMM of every stream on the CURRENT stream (after ``loss.backward()`` returned, i.e.
+    after autograd joined its streams): the long grouped launches then run alone at full efficiency instead of beside --
+    and in the way of -- the other encoder's short dependent dX launches."""
+    pending = []
+    for slot in _wgrad.values():
+        pending.extend(slot[2])
+        slot[2].clear()
+    if pending:
+        _launch_group(pending)
+
+
 def wgrad_join():
     """End of a block backward: every queued weight-gradient GEMM is issued and ordered before what the current stream does
     next (the gradients are about to be handed to autograd)."""
-    if not _wgrad:
+    if not _wgrad or WGRAD_DEFER_TO_STEP_END:
         return
     wgrad_flush()
     cur = torch.cuda.current_stream()
