@@ -183,7 +183,10 @@ def main():
     model = build_model(args.workload, device).train()
     opt = make_optimizer(model, args.torch_optimizer)
     params = [p for p in model.parameters() if p.requires_grad]
-    reducer = GradReducer(params) if world > 1 else None
+    # the fused optimiser applies 1/world itself (grad_prescale): the all-reduced SUM is never rescaled in memory
+    reducer = GradReducer(params, average=args.torch_optimizer) if world > 1 else None
+    if world > 1 and not args.torch_optimizer:
+        opt.grad_prescale = 1.0 / world
     px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
 
     def eager_step():

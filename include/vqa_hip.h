@@ -230,7 +230,9 @@ int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
  * step on the device), so a captured HIP graph of the optimiser step follows the schedule and the step count. */
 int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
                     float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* hyper_dev,
-                    vqa_stream_t s);
+                    float grad_prescale, vqa_stream_t s);
+/* grad_prescale (0 => 1): the gradients in memory are to be read as grad * grad_prescale (norm2 is of the UNscaled values):
+ * data-parallel ranks hand over the all-reduced SUM and 1/world here, so the mean is never written out. */
 /* sum of squares of a fp32 buffer accumulated into out[0] (atomic; caller zeroes) */
 int vqa_sumsq_f32(const float* x, uint64_t n, float* out, vqa_stream_t s);
 

@@ -98,7 +98,8 @@ def _train_worker(rank, world, port, q, mode):
                 opt.step()
                 losses.append(out.loss.item())
         else:
-            red = GradReducer(params, bucket_mb=0.5)
+            red = GradReducer(params, bucket_mb=0.5, average=False)      # the SUM stays in memory, the optimiser applies 1/world
+            opt.grad_prescale = 1.0 / world
             gs = GraphedTrainStep(model, opt, batch, reducer=red, warmup=warm, capture_error_mode='thread_local')
             losses = [float('nan')] * warm + [gs(batch).item() for _ in range(n - warm)]
         torch.cuda.synchronize()

@@ -247,7 +247,7 @@ __global__ void sumsq_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
 // hyper (optional, device): {lr, step}: read at run time so a captured graph follows the schedule and the step count.
 __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uint32_t* __restrict__ chunks, const float* __restrict__ norm2,
                                    float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2,
-                                   const float* __restrict__ hyper) {
+                                   const float* __restrict__ hyper, float prescale) {
     if (hyper) {
         lr = hyper[0];
         const float t = hyper[1];
@@ -257,8 +257,9 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
     const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
     const uint64_t beg = chunks[2 * blockIdx.x + 1];
     const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
-    float gs = 1.f;
-    if (norm2 && max_norm > 0.f) { const float c = max_norm / (sqrtf(norm2[0]) + 1e-6f); gs = c < 1.f ? c : 1.f; }
+    // prescale: the gradients in memory are SUMS over `1/prescale` data-parallel ranks; their mean is never materialised
+    float gs = prescale;
+    if (norm2 && max_norm > 0.f) { const float c = max_norm / (prescale * sqrtf(norm2[0]) + 1e-6f); gs = c < 1.f ? c * prescale : prescale; }
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * j.weight_decay;
     const uint64_t e4 = beg + (end - beg) / 4 * 4;
     for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
@@ -308,10 +309,10 @@ int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
 
 int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
                     float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* hyper_dev,
-                    vqa_stream_t s) {
+                    float grad_prescale, vqa_stream_t s) {
     if (!jobs_dev || !chunks_dev || nchunks <= 0) return VQA_ERR_ARG;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(TPB), 0, (hipStream_t)s, jobs_dev, chunks_dev, norm2, max_norm, lr, beta1, beta2,
-                       eps, bias_correction1, bias_correction2, hyper_dev);
+                       eps, bias_correction1, bias_correction2, hyper_dev, grad_prescale == 0.f ? 1.f : grad_prescale);
     return (int)hipGetLastError();
 }
 

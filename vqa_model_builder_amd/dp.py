@@ -161,7 +161,6 @@ class GradReducer:
         self._presence.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
         pres_work = dist.all_reduce(self._presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         # pack + launch, bucket by bucket
-        self._static = []
         for b in self.buckets:
             srcs, dsts, zero_slots = [], [], []
             for p, off in zip(b.params, b.offsets):
@@ -171,7 +170,6 @@ class GradReducer:
                 else:
                     srcs.append(p.grad.reshape(-1))
                     dsts.append(view)
-            self._static.append((dsts, srcs, zero_slots))
             if zero_slots:
                 torch._foreach_zero_(zero_slots)
             if srcs:
@@ -181,24 +179,58 @@ class GradReducer:
         self._assign(self._presence.tolist())
 
     @torch.no_grad()
+    def prepare_static(self):
+        """HIP-graph mode (graph.GraphedTrainStep), called once after the forward+backward graph was captured: from then on
+        every replay writes the gradients to the SAME addresses.  The block runners' gradient arenas (one storage per encoder /
+        fusion layer, holding every gradient of the block) are all-reduced IN PLACE, whole -- no packing pass, no second copy
+        of 0.9 GB of gradients; the few parameters with a storage of their own are packed into one small buffer and
+        ``p.grad`` re-pointed at it.  The set of present gradients is the capture's (a captured step has no data-dependent
+        control flow)."""
+        by_storage = {}
+        for b in self.buckets:
+            for p in b.params:
+                if p.grad is None:
+                    continue
+                us = p.grad.untyped_storage()
+                by_storage.setdefault(us.data_ptr(), [us, []])[1].append(p)
+        self._inplace, loose = [], []
+        for us, ps in by_storage.values():
+            g0 = ps[0].grad
+            if len(ps) > 1 and all(q.grad.dtype == torch.float32 for q in ps) and us.nbytes() % 4 == 0:
+                self._inplace.append(torch.empty(0, dtype=torch.float32, device=g0.device).set_(us, 0, (us.nbytes() // 4,)))
+            else:
+                loose.extend(ps)
+        self._loose = None
+        if loose:
+            n = sum((q.numel() + 3) // 4 * 4 for q in loose)
+            flat = torch.zeros(n, dtype=torch.float32, device=loose[0].grad.device)
+            dsts, srcs, off = [], [], 0
+            for q in loose:
+                view = flat[off:off + q.numel()]
+                srcs.append(q.grad.reshape(-1))
+                dsts.append(view)
+                q.grad = view.view(q.shape)
+                off += (q.numel() + 3) // 4 * 4
+            self._loose = (flat, dsts, srcs)
+        return self
+
+    @torch.no_grad()
     def reduce_static(self):
-        """HIP-graph mode (graph.GraphedTrainStep): a replayed backward graph rewrites the SAME gradient buffers the last
-        ``reduce()`` packed from, while ``p.grad`` already points at the bucket slices the optimiser graph reads -- so pack
-        from the recorded sources, sum, average; nothing is re-pointed.  The set of present gradients is the capture's
-        (a captured step has no data-dependent control flow, so it cannot change)."""
+        """After every replay of the forward+backward graph: sum (and, with ``average``, scale) the gradients where they lie."""
         if self.world == 1:
             return
-        scale = 1.0 / self.world if self.average else 1.0
-        for b, (dsts, srcs, zero_slots) in zip(self.buckets, self._static):
-            if zero_slots:
-                torch._foreach_zero_(zero_slots)
-            if srcs:
-                torch._foreach_copy_(dsts, srcs)
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for b in self.buckets:
-            b.work.wait()
-            if scale != 1.0:
-                b.flat.mul_(scale)
+        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self._inplace]
+        flats = list(self._inplace)
+        if self._loose is not None:
+            flat, dsts, srcs = self._loose
+            torch._foreach_copy_(dsts, srcs)
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            flats.append(flat)
+        for w in works:
+            w.wait()
+        if self.average and self.world > 1:
+            for f in flats:
+                f.mul_(1.0 / self.world)
 
     def bytes_per_step(self) -> int:
         return sum(b.numel for b in self.buckets) * 4

@@ -66,10 +66,10 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode):
                 self.loss = self._fwd_bwd()
-            # a capture records, it does not run: the gradient buffers hold nothing meaningful yet.  reduce() is called for its
-            # side effects only -- it records where each gradient lives (reduce_static packs from there after every replay)
-            # and re-points p.grad at the bucket slices, the addresses the optimiser graph is captured against.
-            reducer.reduce()
+            # the gradients now have their final, static addresses: the reducer finds the arenas it will all-reduce in place
+            # after every replay (and packs the few stand-alone gradients, re-pointing p.grad) before the optimiser graph
+            # is captured against those addresses
+            reducer.prepare_static()
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=capture_error_mode):
                 self.opt.step()

@@ -88,7 +88,7 @@ SIGNATURES = {
     'vqa_layernorm_reduce_grouped': (i32, [vp, i32, vp]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
-    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
+    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, f32, vp]),
     'vqa_adamw_step': (i32, [C.POINTER(VqaAdamWDesc), vp]),
     'vqa_sumsq_f32': (i32, [vp, u64, vp, vp]),
 }

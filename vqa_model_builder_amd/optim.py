@@ -28,6 +28,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper_inc = None
         self._pending_replays = 0
         self._staging = {}                                # HIP-graph mode: pinned host rows per job table
+        self.grad_prescale = 1.0                          # DP: gradients hold the all-reduced SUM; 1/world is applied here
 
     def attach_shadows(self, model):
         """Lets the update kernel write the bf16 / packed-fp32 weight shadows of the block runners directly."""
@@ -147,11 +148,12 @@ class FusedAdamW(torch.optim.Optimizer):
                 hyper.add_(self._hyper_inc)               # device-side step += 1 (captured with the step)
             K._chk(lib.vqa_adamw_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr() if clip else None,
                                        float(self.max_grad_norm or 0.0), float(group['lr']), b1, b2, group['eps'],
-                                       1.0 - b1 ** step, 1.0 - b2 ** step, hyper.data_ptr() if hyper is not None else None, st),
+                                       1.0 - b1 ** step, 1.0 - b2 ** step, hyper.data_ptr() if hyper is not None else None,
+                                       float(self.grad_prescale), st),
                    'vqa_adamw_multi')
         _ops.bump_shadow_generation()                      # stand-alone bf16 shadows (tail ops) are stale now
         return loss
 
     def grad_norm(self):
         """Global gradient norm of the last clipped step (device scalar)."""
-        return None if self._norm2 is None else self._norm2.sqrt()
+        return None if self._norm2 is None else self._norm2.sqrt() * self.grad_prescale
