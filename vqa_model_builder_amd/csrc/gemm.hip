@@ -781,9 +781,9 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
         flops += 2L * d.M * d.N * d.K;
     }
     // Tile: with thousands of tiles in the grid the per-workgroup DMA rate no longer decides (occupancy is free), bytes per
-    // FLOP does: 128x128 once there are >= 8 rounds of them over the 256 CUs, else the 64x64 tile of the single launches.
+    // FLOP does: 128x128 once there are >= 3 rounds of them over the 256 CUs, else the 64x64 tile of the single launches.
     int tile = g_group_tile;
-    if (tile == 0) tile = t64 / 4 >= 8 * 256 ? 3 : 1;
+    if (tile == 0) tile = t64 / 4 >= 3 * 256 ? 3 : 1;
     const int bm = tile == 1 ? 64 : 128, bn = tile == 3 ? 128 : 64;
     GroupArgs g{};
     g.n = n; g.group_m = g_group_m;
