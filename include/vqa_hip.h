@@ -67,6 +67,8 @@ typedef struct VqaGemmGroupItem {
     int M, N, K, lda, ldb, ldc;
 } VqaGemmGroupItem;
 int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);   /* a_kc == b_kc */
+void vqa_set_gemm_grid_cap(int cap);      /* > 0: LDS-DMA GEMMs run persistent on at most `cap` workgroups (0: one workgroup per tile) */
+void vqa_set_gemm_force(int cfg, int stages);   /* diagnostics: tile id (0: 128x128, 1: 64x64, 4: 128x64, 5: 64x128; -1: heuristics) for every LDS-DMA launch */
 void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
 void vqa_set_gemm_group_m(int g);          /* tile-row group of the L2-aware tile order (default 16; <= 1 = row-major) */

@@ -569,7 +569,14 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
     GemmArgs p = p_in;
     if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
     const int ntiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
-    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, xcd_remap(blockIdx.x, ntiles));
+    // PERSISTENT when the host capped the grid (vqa_set_gemm_grid_cap): workgroup b walks tiles b, b + G, b + 2G ...  A capped
+    // grid leaves LDS / wave slots on every CU for the kernels of an independent launch chain (the other encoder's
+    // branch of the captured graph), so the two chains really run side by side instead of one filling the other's tails.
+    // G is a multiple of 8, so a workgroup's tiles stay on its XCD's contiguous range of the remap.
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, xcd_remap(t, ntiles));
+        __syncthreads();                                     // the ring (epilogue scratch) is free again
+    }
 }
 
 // GROUPED launch: up to MAX_GROUP independent fp32-output GEMMs of one operand layout in ONE grid (the weight-gradient GEMMs
@@ -593,6 +600,8 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const G
     gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
 }
 
+int g_force_cfg = -1, g_force_stages = 2;
+int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
 int g_group_m = 16;
@@ -610,7 +619,9 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p);
+    int grid = tiles;
+    if (g_grid_cap > 0 && splits == 1 && tiles > g_grid_cap) grid = g_grid_cap / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p);
     return (int)hipGetLastError();
 }
 template <int BM, int BN, int WM_, int WN_, int BKT, int ST>
@@ -652,6 +663,8 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_group_m(int g) { g_group_m = g; }
+extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
+extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }
 extern "C" void vqa_set_gemm_pipeline(int v1) {
     // diagnostics for tile_hint launches.  0: register-staged double buffer; 2 / 3: LDS-DMA ring with that many stages
     g_use_v1 = v1 != 0; g_force_dma = v1 != 0;
@@ -700,15 +713,16 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         // of the LDS-DMA ring runs near the CU's L2->LDS rate; what is left is per-launch cost (cold start, C stores), so
         // the choice is about workgroups per CU and bytes per FLOP:
         //   k-contiguous A and a wide N (>= 1536)  -> 128x64 tiles, 2-stage ring (3 workgroups per CU)
-        //   everything else with >= 256 rows       -> 64x64 tiles; 3-stage ring when k is long (>= 2048) and the grid is
-        //                                             under two workgroups per CU (else the third stage costs occupancy)
+        //   everything else with >= 256 rows       -> 64x64 tiles, 3-stage ring (back-to-back microbenchmarks prefer 2 stages
+        //                                             for short k / big grids; inside the step, beside the other encoder's
+        //                                             launches, 3 stages everywhere measured 2 % faster end to end)
         //   small M (< 256)                        -> 64x64 register-staged double buffer
         cfg = 1; dma = false;
         if (d->a_kc && d->M >= 512 && d->N >= 1536) { cfg = 4; dma = true; stages = 2; }
         else if (d->M >= 256 && d->N >= 64) {
-            cfg = 1; dma = true;
-            stages = (d->K >= 2048 && (long)ceil_div(d->M, 64) * ceil_div(d->N, 64) < 512) ? 3 : 2;
+            cfg = 1; dma = true; stages = 3;
         }
+        if (g_force_cfg >= 0 && dma) { cfg = g_force_cfg; stages = g_force_stages; }     // diagnostics (vqa_set_gemm_force)
     }
     const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : 64;
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : 128;
