@@ -142,9 +142,10 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int 
 
 // blockIdx -> output tile.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b gets the
 // tile id  chunk(b % 8) + b / 8  and every XCD (private 4-MiB L2) works on one contiguous range of tile ids.
-// (2) Inside that range tiles are walked in GROUPS of group_m tile-rows, tile-row fastest: the ~160 workgroups an XCD
-// holds at once then cover a group_m x ~10 patch of the output, i.e. they share group_m A-panels and ~10 B-panels that
-// fit the L2 together, instead of one A-panel and EVERY B-panel (which thrashes it and sends each tile to the MALL).
+// (2) Inside that range tiles can be walked in GROUPS of group_m tile-rows, tile-row fastest (the workgroups an XCD holds at
+// once then cover a group_m x ~10 patch of the output: group_m A-panels and ~10 B-panels).  Back-to-back microbenchmarks
+// liked group_m = 8-16 (L2 hit rate 0.87 vs 0.75); inside the training step, with two encoders' launches sharing the L2s, plain
+// row-major order (group_m = 1) is 2 % faster end to end and is the default (vqa_set_gemm_group_m).
 __device__ __forceinline__ int xcd_remap(int t, int ntiles) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective
@@ -604,7 +605,7 @@ int g_force_cfg = -1, g_force_stages = 2;
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
-int g_group_m = 16;
+int g_group_m = 1;         // in-situ sweep (graph step, cfg2): 1 -> 7.70 ms, 2 -> 7.80, 8 -> 7.84, 16 -> 7.89, 32 -> 7.98
 int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
 
 
