@@ -127,6 +127,7 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
  * vqa_layernorm_reduce_grouped sums the partials of up to 32 such calls in ONE launch (a block runner issues it once at the
  * end of its backward instead of one short launch behind every LayerNorm). */
 int vqa_layernorm_bwd_blocks(int rows);
+void vqa_set_layernorm_bwd_blocks(int n);    /* tuning: workgroups of the backward kernel, <= 1024 (default 512) */
 int vqa_layernorm_bwd_partials(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* dres, float* dx_f32, void* dx_bf16, int want_colsum, float* ws, int rows, int cols,
                                float drop_p, uint64_t drop_seed, uint32_t drop_stream, int drop_mode, vqa_stream_t s);

@@ -424,3 +424,74 @@ def test_grouped_weight_gradient_gemm_matches_single_launches():
             assert (g - r).abs().max() <= 1e-4 * exact.abs().max()       # single launches may pick split-K (atomics): not bitwise
     finally:
         K.WGRAD_GROUPED = prev
+
+
+def test_layernorm_backward_deferred_grouped_reduce_and_accumulate_mode():
+    """Three ways to finish LayerNorm backward's reductions -- two-pass (ws), deferred partials + ONE grouped reduce for several
+    calls, accumulate-by-atomics into zeroed outputs -- agree on d-gamma, d-beta and the fused bias-gradient column sums."""
+    rows, cols = 515, 768
+    outs = {}
+    for mode in ('two_pass', 'deferred', 'accumulate'):
+        res = []
+        for seed in (1, 2, 3):
+            x, dy = rnd((rows, cols), seed).to(DEV), rnd((rows, cols), 10 + seed).to(DEV)
+            g, b = (1 + 0.1 * rnd((cols,), 3)).to(DEV), rnd((cols,), 4).to(DEV)
+            _, _, mean, rstd = K.layernorm_fwd(x, g, b, rows, cols)
+            z = lambda: torch.zeros((cols,), device=DEV)
+            dg, db, cs = z(), z(), z()
+            dx, dxb, _, _ = K.layernorm_bwd(dy, x, mean, rstd, g, rows, cols, want_bf16=True, dgamma=dg, dbeta=db, dx_colsum=cs,
+                                            defer=(mode == 'deferred'), accumulate=(mode == 'accumulate'))
+            res.append((dx, dg, db, cs))
+        if mode == 'deferred':
+            assert all(float(r[1].abs().max()) == 0.0 for r in res)          # nothing reduced yet
+            K.ln_reduce_flush()
+        torch.cuda.synchronize()
+        outs[mode] = res
+    for mode in ('deferred', 'accumulate'):
+        for a, b in zip(outs['two_pass'], outs[mode]):
+            assert torch.equal(a[0], b[0])
+            for i in (1, 2, 3):
+                assert torch.allclose(a[i], b[i], atol=2e-3, rtol=1e-4), (mode, i)
+
+
+def test_attention_backward_fused_bias_gradient_sums():
+    """dq/dk/dv column sums accumulated by the attention backward (MFMA kernel: per-workgroup LDS reduction + one atomic per
+    column; generic kernel: separate passes) == column sums of the bf16 gradients it wrote."""
+    for (B, H, Sq, Skv, Dh) in [(4, 12, 50, 50, 64), (3, 8, 64, 40, 96), (2, 4, 100, 100, 32)]:
+        D = H * Dh
+        q, k, v = [rnd((B * s, D), i).to(DEV).to(BF) for i, s in ((1, Sq), (2, Skv), (3, Skv))]
+        do = rnd((B * Sq, D), 4).to(DEV).to(BF)
+        dq = torch.empty((B * Sq, D), dtype=BF, device=DEV)
+        dk, dv = torch.empty((B * Skv, D), dtype=BF, device=DEV), torch.empty((B * Skv, D), dtype=BF, device=DEV)
+        cq, ck, cv = [torch.zeros((D,), device=DEV) for _ in range(3)]
+        K.attention_bwd(q, k, v, do, D, D, D, B, H, Sq, Skv, Dh, dq, dk, dv, D, D, D, dq_colsum=cq, dk_colsum=ck, dv_colsum=cv)
+        for c, t in ((cq, dq), (ck, dk), (cv, dv)):
+            want = t.float().sum(0)
+            assert torch.allclose(c, want, atol=1e-3 * float(want.abs().max()) + 1e-4, rtol=1e-4)
+
+
+def test_fused_adamw_device_side_step_count_and_gradient_prescale():
+    """make_capturable: lr / step count read from device memory (bias correction follows the device counter);
+    grad_prescale s: gradients in memory are s-times too large sums -- same update as averaged gradients, clip included."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    torch.manual_seed(1)
+    shapes = [(33, 17), (257,), (64, 48)]
+    base = [torch.randn(s, device=DEV) for s in shapes]
+    mk = lambda: [torch.nn.Parameter(t.clone()) for t in base]
+    ref, cap, pre = mk(), mk(), mk()
+    o_ref = FusedAdamW(ref, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0)
+    o_cap = FusedAdamW(cap, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0)
+    o_pre = FusedAdamW(pre, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0)
+    o_pre.grad_prescale = 0.25
+    for step in range(5):
+        gs = [torch.randn(s, device=DEV) * (2.0 if step % 2 == 0 else 0.05) for s in shapes]
+        for ps, scale in ((ref, 1.0), (cap, 1.0), (pre, 4.0)):
+            for p, g in zip(ps, gs):
+                p.grad = g * scale
+        if step == 1:
+            o_cap.make_capturable(DEV)                   # from here on the step count lives on the device
+        o_ref.step(); o_cap.step(); o_pre.step()
+    for a, b, c in zip(ref, cap, pre):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+        assert torch.allclose(a, c, atol=2e-6, rtol=2e-5)
+    assert abs(float(o_pre.grad_norm()) - float(o_ref.grad_norm())) < 1e-4 * float(o_ref.grad_norm())

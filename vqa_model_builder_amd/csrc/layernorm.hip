@@ -217,7 +217,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_grouped_kernel(const LnRed
     }
 }
 
-constexpr int BWD_BLOCKS = 256;
+constexpr int BWD_BLOCKS_MAX = 1024;
+int g_bwd_blocks = 512;      // workgroups of the backward kernel (4 waves each); vqa_set_layernorm_bwd_blocks
 
 inline int nv_for(int cols) { return ceil_div(cols / 4, 64); }
 
@@ -241,8 +242,9 @@ int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, cons
     return (int)hipGetLastError();
 }
 
-size_t vqa_layernorm_bwd_ws_floats(int cols) { return (size_t)3 * BWD_BLOCKS * cols; }
-int vqa_layernorm_bwd_blocks(int rows) { return min(ceil_div(rows, WAVES), BWD_BLOCKS); }
+size_t vqa_layernorm_bwd_ws_floats(int cols) { return (size_t)3 * BWD_BLOCKS_MAX * cols; }
+int vqa_layernorm_bwd_blocks(int rows) { return min(ceil_div(rows, WAVES), g_bwd_blocks); }
+void vqa_set_layernorm_bwd_blocks(int n) { g_bwd_blocks = n < 1 ? 1 : n > BWD_BLOCKS_MAX ? BWD_BLOCKS_MAX : n; }
 
 static bool g_ln_defer_reduce = false;     // set around a call by vqa_layernorm_bwd_partials
 
@@ -287,7 +289,7 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
     // guarantees they are initialised (the gradient arena is zero-filled once per backward)
     const bool reduce_out = dgamma || dbeta || dx_colsum;
     const bool accumulate = reduce_out && !ws;
-    const int grid = min(ceil_div(rows, WAVES), BWD_BLOCKS);
+    const int grid = min(ceil_div(rows, WAVES), g_bwd_blocks);
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     float* wsp = (reduce_out && !accumulate) ? ws : nullptr;
     float* ag = accumulate ? dgamma : nullptr; float* ab = accumulate ? dbeta : nullptr; float* ac = accumulate ? dx_colsum : nullptr;
