@@ -200,14 +200,14 @@ def main():
         opt.step()                                   # FusedAdamW: global-norm clip (1.0) + AdamW + bf16 shadow refresh, fused
         return out.loss
 
-    # Single GPU, no MoE (its dispatch reads expert counts on the host): the whole step -- forward, backward, clip, AdamW --
+    # Single GPU: the whole step -- forward, backward, clip, AdamW --
     # is ONE captured HIP graph with the two encoders as parallel branches; every replay copies a batch into the static
     # input buffers, draws fresh dropout masks (device-side RNG epoch) and advances the optimiser's device-side step count.
     # N > 1: forward+backward is one graph, the bucketed RCCL all-reduce is launched eagerly between the replays (collectives
     # stay outside the capture), the optimiser step is a second graph.  Should the capture fail beside an initialised process
     # group (the capture decision is all-or-nothing across ranks) every rank falls back to the eager step with the
     # gradient exchange overlapped into backward by hooks.
-    use_graph = not args.eager and not args.torch_optimizer and WORKLOADS[args.workload][1] == 0
+    use_graph = not args.eager and not args.torch_optimizer
     step = eager_step
     launch = 'eager'
     if use_graph:

@@ -224,6 +224,10 @@ int vqa_adamw_step(const VqaAdamWDesc* d, vqa_stream_t s);
 typedef struct VqaOptJob {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq; void* shadow;
     uint64_t n; float weight_decay; uint32_t shadow_kind;
+    const float* active;     /* optional device word: the job is SKIPPED (parameter, moments, shadow untouched) while *active == 0.
+                              * The captured MoE step runs every expert on every token (no host read of the routing counts);
+                              * an expert no token chose must still be left alone by the optimiser, as the reference's
+                              * grad-is-None skip does -- its routed-token count is this word. */
 } VqaOptJob;
 /* chunks_dev: uint32 [nchunks][2] = {job index, first element}; every chunk covers vqa_opt_chunk_elems() elements of its
  * tensor (the last one of a tensor fewer): one workgroup per chunk keeps the chip streaming whatever the tensor sizes. */

@@ -95,3 +95,80 @@ def test_indirect_seed_matches_between_forward_and_backward():
         assert torch.equal(a, b) and not torch.equal(a, c)
     finally:
         blocks.disable_indirect_seeds()
+
+
+def _moe_setup(seed=7):
+    from oracle import det_weights as dw
+    from oracle.gen_golden import TINY
+    from tests.helpers import build_model
+    from vqa_model_builder_amd.optim import FusedAdamW
+    meta = {'dims': TINY, 'fusion_type': 'cross_attention', 'num_experts': 4}
+    model = build_model(meta)
+    model.load_state_dict(dw.make_state_dict(dw.shapes_of(model.state_dict()), seed))
+    model = model.to('cuda:0').eval()
+    d = TINY
+    px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=d['vocab'], num_answers=d['num_answers'], seed=78)
+    batch = dict(pixel_values=px.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01, max_grad_norm=1.0).attach_shadows(model)
+    return model, opt, batch
+
+
+def test_dense_moe_dispatch_equals_sparse_dispatch():
+    """The capturable MoE dispatch (every expert on every token, routing weights zero where not chosen) against the sparse one:
+    same logits and gradients; where the sparse dispatch skipped an expert the dense one produces exact zeros; the layer's
+    device-side routed-token counts equal the bincount of the router's indices."""
+    sparse, _, batch = _moe_setup()
+    dense, _, _ = _moe_setup()
+    dense.moe_layer.enable_dense_dispatch(True)
+    o_s, o_d = sparse(**batch), dense(**batch)
+    o_s.loss.backward(); o_d.loss.backward()
+    assert torch.allclose(o_s.logits, o_d.logits, atol=2e-3, rtol=2e-3)
+    idx = dense.moe_layer.aux_outputs['expert_indices'].reshape(-1) if 'expert_indices' in dense.moe_layer.aux_outputs else None
+    gs, gd = dict(sparse.named_parameters()), dict(dense.named_parameters())
+    for n in gs:
+        if gs[n].grad is None:
+            assert gd[n].grad is None or float(gd[n].grad.abs().max()) == 0.0, n
+        else:
+            a, b = gs[n].grad.float(), gd[n].grad.float()
+            assert (a - b).norm() <= 5e-2 * a.norm() + 1e-6, n
+    act = dense.moe_layer._active.cpu()
+    assert float(act.sum()) == batch['labels'].shape[0] * dense.moe_layer.top_k        # one token per sample, top-k slots each
+    if idx is not None:
+        assert torch.equal(act, torch.bincount(idx.cpu().clamp(min=0), minlength=len(act)).float())
+
+
+def test_fused_adamw_skips_parameters_of_an_expert_without_tokens():
+    """`_vqa_active` (device word, the expert's routed-token count): 0 -> the parameter, its moments and its shadow are left
+    alone (the reference's grad-is-None skip); > 0 -> normal update.  Also under a replayed graph."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    a, b = torch.nn.Parameter(torch.randn(300, 7, device='cuda')), torch.nn.Parameter(torch.randn(129, device='cuda'))
+    act = torch.zeros(2, device='cuda')
+    a._vqa_active, b._vqa_active = act[0:1], act[1:2]
+    opt = FusedAdamW([a, b], lr=1e-2, weight_decay=0.1, max_grad_norm=1.0)
+    a0, b0 = a.detach().clone(), b.detach().clone()
+    a.grad, b.grad = torch.randn_like(a), torch.randn_like(b)
+    act.copy_(torch.tensor([0.0, 5.0]))
+    opt.step()
+    assert torch.equal(a.detach(), a0) and not torch.equal(b.detach(), b0)
+    assert float(opt.state[a]['exp_avg'].abs().max()) == 0.0
+    act.copy_(torch.tensor([2.0, 0.0]))
+    b1 = b.detach().clone()
+    opt.step()
+    assert not torch.equal(a.detach(), a0) and torch.equal(b.detach(), b1)
+
+
+def test_moe_model_trains_under_a_replayed_graph():
+    from vqa_model_builder_amd.graph import GraphedTrainStep
+    from vqa_model_builder_amd.hip import blocks
+    try:
+        ref_model, ref_opt, batch = _moe_setup()
+        ref = _eager(ref_model, ref_opt, batch, 6)
+        model, opt, _ = _moe_setup()
+        gs = GraphedTrainStep(model, opt, batch, warmup=2)
+        got = [gs(batch).item() for _ in range(4)]
+        assert ref[0] - ref[-1] > 0.02, ref
+        for x, y in zip(ref[2:], got):
+            assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), (ref, got)
+    finally:
+        blocks.disable_indirect_seeds()

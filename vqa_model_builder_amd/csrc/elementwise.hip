@@ -255,6 +255,7 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
         bc2 = 1.f - powf(beta2, t);
     }
     const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
+    if (j.active && j.active[0] == 0.f) return;          // expert no token was routed to: skipped like a grad-is-None parameter
     const uint64_t beg = chunks[2 * blockIdx.x + 1];
     const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
     // prescale: the gradients in memory are SUMS over `1/prescale` data-parallel ranks; their mean is never materialised

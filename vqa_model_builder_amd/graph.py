@@ -12,8 +12,9 @@ What makes a replay a real training step and not a re-run of the captured one:
     (csrc/common.h ``resolve_seed``), so every replay draws fresh masks and backward regenerates the forward's;
   * the optimiser's learning rate and step count live in device memory and are advanced inside the graph
     (``FusedAdamW.make_capturable``), so bias correction and schedules follow the real step number.
-Data-dependent host decisions (the MoE dispatch reads its per-expert counts on the host) cannot be captured: models
-with MoE layers run eagerly.  With data parallelism the gradient exchange stays outside the graph (forward+backward is one
+Data-dependent host decisions cannot be captured: the MoE layers switch to their dense dispatch (every expert on every
+token, combined with the routing weights -- exact, and free at one token per sample; see modeling/moe/moe_layer.py), and an
+expert no token chose is skipped by the optimiser through a device-side routed-token count instead of a ``grad is None``.  With data parallelism the gradient exchange stays outside the graph (forward+backward is one
 graph, the all-reduce is launched eagerly, the optimiser step is a second graph).
 """
 
@@ -40,6 +41,9 @@ class GraphedTrainStep:
         _blocks.enable_indirect_seeds(dev)
         if parallel_towers and hasattr(model, 'encode_visual'):
             model.parallel_towers = True
+        for m in model.modules():                      # MoE layers: dispatch without the host read of the routing counts
+            if hasattr(m, 'enable_dense_dispatch'):
+                m.enable_dense_dispatch(True)
         self._wgrad_side = wgrad_side_stream
         self._defer_wgrad = defer_wgrad
         cur = torch.cuda.current_stream()
@@ -96,6 +100,10 @@ class GraphedTrainStep:
         self.g_main.replay()
         if self.g_opt is not None:
             self.reducer.reduce_static()
+            for m in self.model.modules():              # an expert is active when ANY rank routed a token to it
+                a = getattr(m, '_active', None)
+                if a is not None and getattr(m, 'dense_dispatch', False):
+                    torch.distributed.all_reduce(a)
             self.g_opt.replay()
         if hasattr(self.opt, 'note_replays'):
             self.opt.note_replays(1)

@@ -108,6 +108,45 @@ class MOELayer(nn.Module):
         self.output_norm = nn.LayerNorm(output_dim)
         self.aux_outputs: Dict[str, Any] = {}
 
+    # ---- dense dispatch (HIP-graph mode) -----------------------------------------------------------------------------
+    # The sparse dispatch reads the per-expert token counts on the host (the reference syncs per expert, moe_layer.py:156):
+    # a captured graph cannot.  On this path the MoE sees ONE token per sample (the fused vector, S = 1) and every expert's
+    # GEMMs have M <= batch rows -- they are bound by reading the expert's weights, not by its rows -- so running every expert
+    # on every token and combining with the routing weights (zero where an expert was not chosen) costs no time and needs no
+    # host decision.  Outputs and gradients are those of the sparse dispatch; an expert NO token chose gets zero gradients
+    # instead of none, and its parameters carry `_vqa_active` (device word = its routed-token count) so that FusedAdamW
+    # leaves them alone exactly as it skips a grad-is-None parameter.
+    dense_dispatch = False
+
+    def enable_dense_dispatch(self, on: bool = True):
+        self.dense_dispatch = on
+        if on and getattr(self, '_active', None) is None:
+            dev = self.output_norm.weight.device
+            self._active = torch.ones((len(self.experts),), dtype=torch.float32, device=dev)
+            for e, expert in enumerate(self.experts):
+                for prm in expert.parameters():
+                    prm._vqa_active = self._active[e:e + 1]
+        return self
+
+    def _forward_dense(self, x, mask, w2, i2, B, S, D, kwargs):
+        T, E = B * S, len(self.experts)
+        valid = i2 >= 0                                           # -1 routes nowhere (ablation harness contract)
+        idx = i2.clamp(min=0)
+        w_all = torch.zeros((T, E), dtype=torch.float32, device=x.device).scatter_add(1, idx, w2 * valid)
+        with torch.no_grad():
+            self._active.copy_(torch.zeros((E,), dtype=torch.float32, device=x.device).scatter_add_(
+                0, idx.reshape(-1), valid.reshape(-1).float()))
+        out = None
+        for e, expert in enumerate(self.experts):
+            if S == 1 or expert.token_local:
+                ye = expert(x.reshape(T, 1, D), **kwargs)
+            else:
+                ye = expert(x, mask=mask, **kwargs)
+            ye = ye.reshape(T, self.output_dim) * w_all[:, e:e + 1]
+            out = ye if out is None else out + ye
+        out = ops.layer_norm(out, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
+        return out.view(B, S, self.output_dim)
+
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError('MOELayer: HIP path needs GPU tensors; no CPU fallback on the product path')
@@ -119,6 +158,8 @@ class MOELayer(nn.Module):
         w2 = routing_weights.reshape(T, Kk).contiguous().float()
         i2 = expert_indices.reshape(T, Kk).contiguous().long()
         dev = x.device
+        if self.dense_dispatch:
+            return self._forward_dense(x, mask, w2, i2, B, S, D, kwargs)
         w_all = torch.empty((E, T), dtype=torch.float32, device=dev)
         lists = torch.empty((E, T), dtype=torch.int32, device=dev)
         counts_dev = torch.empty((E,), dtype=torch.int32, device=dev)

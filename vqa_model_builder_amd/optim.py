@@ -104,8 +104,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 state['step'] = int(state['step']) + 1
                 sp, sk = shadows.get(id(p), (0, 0))
                 wd_kind = struct.unpack('<q', struct.pack('<fI', float(group['weight_decay']), sk))[0]
+                act = getattr(p, '_vqa_active', None)       # device word: routed-token count of the parameter's expert (dense MoE dispatch)
                 launches.setdefault((gi, state['step']), []).append(
-                    (p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind))
+                    (p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
+                     act.data_ptr() if act is not None else 0))
                 dev = p.device
         if not launches:
             return loss
