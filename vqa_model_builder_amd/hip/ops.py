@@ -36,6 +36,22 @@ def shadow_of(param: torch.Tensor) -> torch.Tensor:
     return ent[1]
 
 
+def standalone_shadow(param: torch.Tensor):
+    """The cached bf16 copy of a stand-alone parameter if one exists for its current storage (a fused optimiser writes it in
+    the same pass as the parameter instead of leaving a cast launch to the next forward), else None."""
+    ent = _shadow_cache.get(id(param))
+    if ent is None or ent[2]() is not param or ent[0][0] != param.data_ptr() or ent[0][2] != param.device:
+        return None
+    return ent[1]
+
+
+def mark_shadow_fresh(param: torch.Tensor):
+    """The optimiser has just written ``standalone_shadow(param)``: the next ``shadow_of`` must not re-cast it."""
+    ent = _shadow_cache.get(id(param))
+    if ent is not None:
+        _shadow_cache[id(param)] = ((param.data_ptr(), param._version, param.device, _shadow_generation), ent[1], ent[2])
+
+
 def _as_bf16(x):
     return x if x.dtype == BF16 else K.cast_bf16(x.float() if x.dtype != F32 else x)
 

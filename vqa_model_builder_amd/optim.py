@@ -89,6 +89,7 @@ class FusedAdamW(torch.optim.Optimizer):
         lib, st = K.L(), K._stream()
         shadows = self._shadow_map()
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
+        standalone = []
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
                 g = p.grad
@@ -103,6 +104,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state['step'] = int(state['step']) + 1
                 sp, sk = shadows.get(id(p), (0, 0))
+                if sp == 0:                                 # stand-alone parameter (tail ops, experts): its cached bf16 copy, if any
+                    sh = _ops.standalone_shadow(p)
+                    if sh is not None and sh.numel() == p.numel():
+                        sp, sk = sh.data_ptr(), 0
+                        standalone.append(p)
                 wd_kind = struct.unpack('<q', struct.pack('<fI', float(group['weight_decay']), sk))[0]
                 act = getattr(p, '_vqa_active', None)       # device word: routed-token count of the parameter's expert (dense MoE dispatch)
                 launches.setdefault((gi, state['step']), []).append(
@@ -153,7 +159,9 @@ class FusedAdamW(torch.optim.Optimizer):
                                        1.0 - b1 ** step, 1.0 - b2 ** step, hyper.data_ptr() if hyper is not None else None,
                                        float(self.grad_prescale), st),
                    'vqa_adamw_multi')
-        _ops.bump_shadow_generation()                      # stand-alone bf16 shadows (tail ops) are stale now
+        _ops.bump_shadow_generation()                      # stand-alone bf16 shadows this step did not write are stale now
+        for p in standalone:
+            _ops.mark_shadow_fresh(p)
         return loss
 
     def grad_norm(self):
