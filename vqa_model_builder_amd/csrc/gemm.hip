@@ -703,14 +703,16 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.colsum = d->colsum;
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
-    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128, 6: 256x128 (8 waves)
+    int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128, 6: 256x128 (8 waves), 7: 32x32, 8: 32x64
     bool dma = g_use_v1;     // LDS-DMA pipeline vs register-staged double buffer
     int stages = g_v1_stages;
     if (d->tile_hint > 0) cfg = d->tile_hint - 1;
+    else if (d->M <= 32 && d->N >= 64) { cfg = 7; dma = true; stages = 3; }     // skinny M (answer head, experts at one token per sample):
+                                                                                 // 32x32 tiles for workgroups, LDS-DMA ring for the long k (9 vs 18 us at 2048^2)
     else if (d->M <= 32) cfg = 2;
     else if (d->N <= 32) cfg = 3;
     else {
-        // Measured on MI355X (profiles/r01/gemm_tiles.log, in-kernel timelines in profiles/r01/gemm_timeline.md).  The k loop
+        // Measured on MI355X (profiles/r01/gemm_tiles.log, in-kernel timelines in profiles/r01/gemm_pmc.md).  The k loop
         // of the LDS-DMA ring runs near the CU's L2->LDS rate; what is left is per-launch cost (cold start, C stores), so
         // the choice is about workgroups per CU and bytes per FLOP:
         //   k-contiguous A and a wide N (>= 1536)  -> 128x64 tiles, 2-stage ring (3 workgroups per CU)
@@ -725,8 +727,8 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         }
         if (g_force_cfg >= 0 && dma) { cfg = g_force_cfg; stages = g_force_stages; }     // diagnostics (vqa_set_gemm_force)
     }
-    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : 64;
-    const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : 128;
+    const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : cfg >= 7 ? 32 : 64;
+    const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : cfg == 7 ? 32 : cfg == 8 ? 64 : 128;
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
 
     int splits = d->split_k;
@@ -749,6 +751,8 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     if (cfg == 6) return launch_v1<256, 128, 4, 2>(p, d->a_kc, d->b_kc, splits, 2, stream);
     if ((dma || g_force_dma) && g_use_tr && cfg != 2 && cfg != 3) {
         switch (cfg) {
+            case 7: return launch_v1<32, 32, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
+            case 8: return launch_v1<32, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
             case 0: return launch_v1<128, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
             case 1: return launch_v1<64, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
             case 4: return launch_v1<128, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stages, stream);
@@ -761,6 +765,8 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         case 2: return launch_cfg<32, 128, 1, 4>(p, d->a_kc, d->b_kc, splits, stream);
         case 3: return launch_cfg<128, 32, 4, 1>(p, d->a_kc, d->b_kc, splits, stream);
         case 4: return launch_cfg<128, 64, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
+        case 7: return launch_cfg<32, 32, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
+        case 8: return launch_cfg<32, 64, 1, 4>(p, d->a_kc, d->b_kc, splits, stream);
         default: return launch_cfg<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
     }
 }
