@@ -259,13 +259,27 @@ def main():
         # instrumented re-run of the same step: every launch of the MFMA GEMM kernel (the dominant kernel: >95 % of the
         # path's FLOPs) is bracketed by HIP events on the stream it is launched on
         model.parallel_towers = False                # one launch chain: each GEMM's own duration, not its share of an overlap
+        # GEMM launches inside the fusion block (forward and backward) are labelled: BASELINE's metric also names the MFMA
+        # utilisation of the cross-attention fusion
+        def _tag(v):
+            def hook(*_a):
+                K.PROFILE_TAG = v
+            return hook
+        hooks = [model.fusion.register_forward_pre_hook(_tag('fusion')), model.fusion.register_forward_hook(_tag('')),
+                 model.fusion.register_full_backward_pre_hook(_tag('fusion')), model.fusion.register_full_backward_hook(_tag(''))]
         K.GEMM_PROFILE = []
         eager_step()
         eager_step()
         torch.cuda.synchronize()
+        for h in hooks:
+            h.remove()
+        K.PROFILE_TAG = ''
         prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
-        tot_flop = sum(f for f, _, _ in prof)
-        tot_ms = sum(a.elapsed_time(b) for _, a, b in prof)
+        tot_flop = sum(p_[0] for p_ in prof)
+        tot_ms = sum(p_[1].elapsed_time(p_[2]) for p_ in prof)
+        fus_flop = sum(p_[0] for p_ in prof if p_[3] == 'fusion')
+        fus_ms = sum(p_[1].elapsed_time(p_[2]) for p_ in prof if p_[3] == 'fusion')
+        fus = fus_flop / (fus_ms * 1e-3) / 1e12 if fus_ms > 0 else None
         ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process; they were collected with
         # rocprofv3 on this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) and committed
@@ -280,6 +294,9 @@ def main():
                     'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                     'traffic_unit': 'B/launch (HBM side)', 'traffic_source': traffic_src,
                     'launches_per_step': len(prof) // 2, 'gemm_ms_per_step': round(tot_ms / 2, 3),
+                    'fusion_gemm_tflops': None if fus is None else round(fus, 2),
+                    'fusion_mfma_util': None if fus is None else round(fus / PEAK_BF16_TFLOPS, 4),
+                    'fusion_gemm_ms_per_step': round(fus_ms / 2, 3),
                     'gemm_gflop_per_step': round(tot_flop / 2 / 1e9, 1),
                     'whole_step_tflops': round(GFLOP_PER_SAMPLE[args.workload] * args.batch / (ms * 1e-3) / 1e3, 2)}
 

@@ -21,3 +21,29 @@ def model_config_from_dims(d, fusion_type, num_experts, pooling='cls'):
 
 def build_model(meta):
     return VietnameseVQAModel(model_config_from_dims(meta['dims'], meta['fusion_type'], meta['num_experts']))
+
+
+def collect_from_workers(q, procs, n, timeout=180):
+    """Reads ``n`` results from the multiprocessing queue ``q``; fails at once (instead of sitting out the queue timeout in
+    silence) when a worker has exited with an error, and after ``timeout`` seconds overall."""
+    import queue as _queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=2))
+            continue
+        except _queue.Empty:
+            pass
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        if dead:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f'worker process exited with {dead}')
+        if time.time() - t0 > timeout:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f'no result from the workers within {timeout} s')
+    return out

@@ -56,10 +56,8 @@ def test_grad_reducer_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = {}
-    for _ in range(2):
-        rank, local, out = q.get(timeout=120)
-        res[rank] = (local, out)
+    from tests.helpers import collect_from_workers
+    res = {rank: (local, out) for rank, local, out in collect_from_workers(q, procs, 2)}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -115,7 +113,8 @@ def test_overlap_hooks_world2_gloo():
     procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    from tests.helpers import collect_from_workers
+    res = dict(collect_from_workers(q, procs, 2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

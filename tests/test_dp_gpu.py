@@ -50,10 +50,8 @@ def test_model_gradients_average_across_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = {}
-    for _ in range(2):
-        rank, local, reduced = q.get(timeout=120)
-        res[rank] = (local, reduced)
+    from tests.helpers import collect_from_workers
+    res = {rank: (local, reduced) for rank, local, reduced in collect_from_workers(q, procs, 2)}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -118,10 +116,8 @@ def _run_two(mode):
     procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
-    res = {}
-    for _ in range(2):
-        rank, losses, sig = q.get(timeout=240)
-        res[rank] = (losses, sig)
+    from tests.helpers import collect_from_workers
+    res = {rank: (losses, sig) for rank, losses, sig in collect_from_workers(q, procs, 2)}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -27,13 +27,13 @@ from .hip import blocks as _blocks
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
-                 reducer=None, warmup: int = 3, parallel_towers: bool = True, wgrad_side_stream: bool = False,
+                 reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).  ``loss_of(output)`` picks the
         scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer`` in NON-overlap mode.
         ``parallel_towers``: the vision encoder runs as a parallel branch of the graph (measured on MI355X, cfg2, B=32:
-        13.7 -> 10.6 ms/step).  ``wgrad_side_stream``: weight-gradient GEMMs as further parallel branches -- measured
-        SLOWER (14.2 ms: ~110 extra cross-branch edges per step cost more than the overlap returns), so off by default."""
+        13.7 -> 10.6 ms/step).  ``defer_wgrad``: the weight-gradient GEMMs of both encoders are issued (grouped) after
+        backward returned, where they run alone at full efficiency."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.loss_of = loss_of or (lambda out: out.loss)
         self.static = {k: v.clone() for k, v in batch.items()}
@@ -44,7 +44,6 @@ class GraphedTrainStep:
         for m in model.modules():                      # MoE layers: dispatch without the host read of the routing counts
             if hasattr(m, 'enable_dense_dispatch'):
                 m.enable_dense_dispatch(True)
-        self._wgrad_side = wgrad_side_stream
         self._defer_wgrad = defer_wgrad
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -82,7 +81,6 @@ class GraphedTrainStep:
         from .hip import kernels as K
         _blocks.advance_rng_epoch()
         self.opt.zero_grad(set_to_none=True)
-        prev, K.WGRAD_SIDE_STREAM = K.WGRAD_SIDE_STREAM, self._wgrad_side
         prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
             out = self.model(**self.static)
@@ -90,7 +88,7 @@ class GraphedTrainStep:
             loss.backward()
             K.wgrad_flush_all()
         finally:
-            K.WGRAD_SIDE_STREAM, K.WGRAD_DEFER_TO_STEP_END = prev, prev_defer
+            K.WGRAD_DEFER_TO_STEP_END = prev_defer
         return loss.detach()
 
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:

@@ -52,6 +52,7 @@ NO_DROP = Drop()
 
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream: (flop, start, end)
 GEMM_PROFILE = None
+PROFILE_TAG = ''        # bench.py: region label attached to each GEMM_PROFILE entry ('fusion' inside the cross-attention fusion block)
 
 
 def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=None, pre_bf16=None, bias=None,
@@ -75,7 +76,7 @@ def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=N
         e0.record()
         _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
         e1.record()
-        GEMM_PROFILE.append((2.0 * M * N * K, e0, e1))
+        GEMM_PROFILE.append((2.0 * M * N * K, e0, e1, PROFILE_TAG))
         return
     _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
 
@@ -111,12 +112,11 @@ def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, resi
 # wgrad_flush() issues everything queued as grouped launches (vqa_gemm_bf16_grouped: up to 32 GEMMs per grid) and the block
 # runner calls it once, at the end of its backward.  One launch then pays one cold start and one tail for a whole encoder's
 # weight gradients and its tens of thousands of equal tiles fill every CU, where a lone 768 x 768 output has 144 tiles.
-# Operands are kept alive until the flush.  WGRAD_SIDE_STREAM additionally moves the grouped launches to a side HIP stream
-# (one cross-stream edge per flush); measured no gain beside the parallel encoder branches, so it is off by default.
+# Operands are kept alive (referenced by the queue) until the flush.  (Issuing them on a side HIP stream instead -- per GEMM, per
+# layer or per flush -- measured slower or no faster beside the parallel encoder branches and is not offered.)
 WGRAD_GROUPED = True
-WGRAD_SIDE_STREAM = False
 WGRAD_GROUP_MAX = 32
-_wgrad = {}          # main cuda_stream handle -> [side torch.cuda.Stream | None, keep-alive list, pending GEMM argument tuples]
+_wgrad = {}          # main cuda_stream handle -> [unused, unused, pending GEMM argument tuples]
 _group_items = None
 
 
@@ -145,7 +145,7 @@ def _launch_group(pending):
         _chk(L().vqa_gemm_bf16_grouped(_group_items, len(chunk), 0, 0, _stream()), 'vqa_gemm_bf16_grouped')
         if GEMM_PROFILE is not None:
             e1.record()
-            GEMM_PROFILE.append((sum(2.0 * a[2] * a[3] * a[4] for a in chunk), e0, e1))
+            GEMM_PROFILE.append((sum(2.0 * a[2] * a[3] * a[4] for a in chunk), e0, e1, 'wgrad'))
 
 
 def wgrad_flush():
@@ -156,15 +156,7 @@ def wgrad_flush():
     slot = _wgrad.get(cur.cuda_stream)
     if slot is None or not slot[2]:
         return
-    if WGRAD_SIDE_STREAM:
-        if slot[0] is None:
-            slot[0] = torch.cuda.Stream()
-        slot[0].wait_stream(cur)
-        with torch.cuda.stream(slot[0]):
-            _launch_group(slot[2])
-        slot[1].extend(t for a in slot[2] for t in (a[0], a[1], a[7]))
-    else:
-        _launch_group(slot[2])
+    _launch_group(slot[2])
     slot[2].clear()
 
 
@@ -189,11 +181,6 @@ def wgrad_join():
     if not _wgrad or WGRAD_DEFER_TO_STEP_END:
         return
     wgrad_flush()
-    cur = torch.cuda.current_stream()
-    slot = _wgrad.get(cur.cuda_stream)
-    if slot is not None and slot[1]:
-        cur.wait_stream(slot[0])
-        slot[1].clear()
 
 
 def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
