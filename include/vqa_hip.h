@@ -240,6 +240,11 @@ int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
                     float grad_prescale, vqa_stream_t s);
 /* grad_prescale (0 => 1): the gradients in memory are to be read as grad * grad_prescale (norm2 is of the UNscaled values):
  * data-parallel ranks hand over the all-reduced SUM and 1/world here, so the mean is never written out. */
+/* nn.Bilinear (fusion_type='bilinear', vqa_model.py:348-351): y = z W^T with z[b, i*D2+j] = x1[b,i]*x2[b,j] (bf16, one GEMM over
+ * K = D1*D2) -- vqa_outer_bf16 builds z; vqa_outer_bwd contracts dz = dy W back: dx1[b,i] = <dz[b,i,:], x2[b]>, dx2[b,j] =
+ * sum_i dz[b,i,j] x1[b,i].  D2 % 4 == 0. */
+int vqa_outer_bf16(const float* x1, const float* x2, void* z_bf16, int B, int D1, int D2, vqa_stream_t s);
+int vqa_outer_bwd(const float* dz, const float* x1, const float* x2, float* dx1, float* dx2, int B, int D1, int D2, vqa_stream_t s);
 /* sum of squares of a fp32 buffer accumulated into out[0] (atomic; caller zeroes) */
 int vqa_sumsq_f32(const float* x, uint64_t n, float* out, vqa_stream_t s);
 

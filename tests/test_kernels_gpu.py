@@ -495,3 +495,24 @@ def test_fused_adamw_device_side_step_count_and_gradient_prescale():
         assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
         assert torch.allclose(a, c, atol=2e-6, rtol=2e-5)
     assert abs(float(o_pre.grad_norm()) - float(o_ref.grad_norm())) < 1e-4 * float(o_ref.grad_norm())
+
+
+def test_bilinear_as_one_gemm_over_outer_products():
+    """ops.bilinear (fusion_type='bilinear') against torch.nn.functional.bilinear in fp32: forward and all three gradients;
+    the operand z = x1 x2^T and the weight are rounded to bf16, hence bf16-level tolerances."""
+    from vqa_model_builder_amd.hip import ops
+    torch.manual_seed(2)
+    for B, D1, D2, Do in [(3, 64, 64, 64), (32, 96, 128, 40)]:
+        x1 = torch.randn(B, D1, device=DEV, requires_grad=True)
+        x2 = torch.randn(B, D2, device=DEV, requires_grad=True)
+        w = torch.nn.Parameter(torch.randn(Do, D1, D2, device=DEV) / math.sqrt(D1 * D2))
+        b = torch.nn.Parameter(torch.randn(Do, device=DEV))
+        y = ops.bilinear(x1, x2, w, b)
+        ref = torch.nn.functional.bilinear(x1.detach().requires_grad_(True), x2.detach().requires_grad_(True), w.detach().requires_grad_(True), b)
+        assert (y - ref).norm() <= 1e-2 * ref.norm()
+        dy = torch.randn_like(y)
+        gx1, gx2, gw = torch.autograd.grad(y, [x1, x2, w], dy)
+        x1r, x2r, wr = [t.detach().clone().requires_grad_(True) for t in (x1, x2, w)]
+        rx1, rx2, rw = torch.autograd.grad(torch.nn.functional.bilinear(x1r, x2r, wr, b.detach()), [x1r, x2r, wr], dy)
+        for g, r in ((gx1, rx1), (gx2, rx2), (gw, rw)):
+            assert (g - r).norm() <= 2e-2 * r.norm(), ((g - r).norm() / r.norm()).item()

@@ -135,7 +135,7 @@ def run_case(tag, rich, with_oracle=False):
     return report
 
 
-@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4'])
+@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_bilinear'])
 def test_tiny_against_reference_golden_and_oracle(tag):
     run_case(tag, True, with_oracle=True)
 

@@ -294,11 +294,61 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
     }
 }
 
+// ---- nn.Bilinear as a GEMM: z[b, i*D2 + j] = x1[b,i] * x2[b,j] (bf16 operand of y = z W^T), and the contraction of dz back ----
+__global__ void outer_bf16_kernel(const float* __restrict__ x1, const float* __restrict__ x2, bf16_t* __restrict__ z, int B, int D1, int D2) {
+    const size_t n = (size_t)B * D1 * D2 / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+        const size_t e = q * 4;
+        const int j = (int)(e % D2), i = (int)((e / D2) % D1), b = (int)(e / ((size_t)D1 * D2));
+        const float a = x1[(size_t)b * D1 + i];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x2 + (size_t)b * D2 + j);
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(a * v[r]);
+        *reinterpret_cast<bf16x4*>(z + e) = o;
+    }
+}
+// dx1[b,i] = sum_j dz[b,i,j] x2[b,j]: one wave per (b,i) row of dz
+__global__ void outer_bwd_x1_kernel(const float* __restrict__ dz, const float* __restrict__ x2, float* __restrict__ dx1, int rows, int D1, int D2) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / D1;
+    float acc = 0.f;
+    for (int j = 4 * lane; j < D2; j += 256) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dz + (size_t)row * D2 + j);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x2 + (size_t)b * D2 + j);
+        acc += d[0] * v[0] + d[1] * v[1] + d[2] * v[2] + d[3] * v[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dx1[row] = acc;
+}
+// dx2[b,j] = sum_i dz[b,i,j] x1[b,i]: thread per column j, coalesced walk down the D1 rows
+__global__ void outer_bwd_x2_kernel(const float* __restrict__ dz, const float* __restrict__ x1, float* __restrict__ dx2, int D1, int D2) {
+    const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D2) return;
+    float acc = 0.f;
+    for (int i = 0; i < D1; ++i) acc += dz[((size_t)b * D1 + i) * D2 + j] * x1[(size_t)b * D1 + i];
+    dx2[(size_t)b * D2 + j] = acc;
+}
+
 }  // namespace
 
 extern "C" {
 
 int vqa_abi_version(void) { return 1; }
+int vqa_outer_bf16(const float* x1, const float* x2, void* z_bf16, int B, int D1, int D2, vqa_stream_t s) {
+    if (!x1 || !x2 || !z_bf16 || B <= 0 || D1 <= 0 || D2 <= 0 || D2 % 4) return VQA_ERR_ARG;
+    const size_t n4 = (size_t)B * D1 * D2 / 4;
+    hipLaunchKernelGGL(outer_bf16_kernel, dim3(grid_for(n4)), dim3(TPB), 0, (hipStream_t)s, x1, x2, (bf16_t*)z_bf16, B, D1, D2);
+    return (int)hipGetLastError();
+}
+int vqa_outer_bwd(const float* dz, const float* x1, const float* x2, float* dx1, float* dx2, int B, int D1, int D2, vqa_stream_t s) {
+    if (!dz || !x1 || !x2 || !dx1 || !dx2 || B <= 0 || D1 <= 0 || D2 <= 0 || D2 % 4) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(outer_bwd_x1_kernel, dim3(ceil_div(B * D1, 4)), dim3(256), 0, (hipStream_t)s, dz, x2, dx1, B * D1, D1, D2);
+    hipLaunchKernelGGL(outer_bwd_x2_kernel, dim3(ceil_div(D2, 256), B), dim3(256), 0, (hipStream_t)s, dz, x1, dx2, D1, D2);
+    return (int)hipGetLastError();
+}
+
 
 int vqa_opt_chunk_elems(void) { return (int)OPT_CHUNK; }
 

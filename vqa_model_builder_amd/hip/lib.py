@@ -89,6 +89,8 @@ SIGNATURES = {
     'vqa_set_layernorm_bwd_blocks': (None, [i32]),
     'vqa_layernorm_bwd_partials': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, u64, u32, i32, vp]),
     'vqa_layernorm_reduce_grouped': (i32, [vp, i32, vp]),
+    'vqa_outer_bf16': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_outer_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
     'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, f32, vp]),

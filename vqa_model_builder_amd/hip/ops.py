@@ -285,8 +285,49 @@ def add(a, b):
     return _AddFn.apply(a, b.expand_as(a) if b.shape != a.shape else b)
 
 
+class _BilinearFn(torch.autograd.Function):
+    """y[b,o] = x1[b] W[o] x2[b]: ONE GEMM over K = D1*D2 with the outer products z[b] = x1[b] x2[b]^T as the bf16 operand
+    (M = batch rows, so it streams the weight once: split-K over the 590k-long reduction fills the CUs)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight):
+        B, D1 = x1.shape
+        D2, Do = x2.shape[1], weight.shape[0]
+        x1c, x2c = x1.contiguous().float(), x2.contiguous().float()
+        z = torch.empty((B, D1 * D2), dtype=BF16, device=x1.device)
+        K._chk(K.L().vqa_outer_bf16(x1c.data_ptr(), x2c.data_ptr(), z.data_ptr(), B, D1, D2, K._stream()), 'vqa_outer_bf16')
+        w = shadow_of(weight).view(Do, D1 * D2)
+        y = torch.zeros((B, Do), dtype=F32, device=x1.device)
+        K.gemm(z, w, B, Do, D1 * D2, D1 * D2, D1 * D2, True, True, out_f32=y, allow_split_k=True, c_prezeroed=True)
+        ctx.save_for_backward(x1c, x2c, z, w)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, z, w = ctx.saved_tensors
+        B, D1 = x1.shape
+        D2 = x2.shape[1]
+        Do = dy.shape[1]
+        dyb = K.cast_bf16(dy.contiguous().float())
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = K.linear_dw(dyb, z, B, Do, D1 * D2).view(ctx.wshape)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dz, _ = K.linear_dx(dyb, w, B, Do, D1 * D2, want_f32=True)
+            dx1 = torch.empty_like(x1)
+            dx2 = torch.empty_like(x2)
+            K._chk(K.L().vqa_outer_bwd(dz.data_ptr(), x1.data_ptr(), x2.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), B, D1, D2, K._stream()),
+                   'vqa_outer_bwd')
+        return dx1, dx2, dw
+
+
 def bilinear(x1, x2, weight, bias):
-    """nn.Bilinear fusion branch (reference vqa_model.py:348-351,404-415): y[b,o] = x1[b] W[o] x2[b] + bias[o].
-    U[b,(o,i)] = <x2[b], W[o,i,:]> is one GEMM (N = out*in1), the remaining contraction with x1 a row-wise dot."""
-    raise NotImplementedError("fusion_type='bilinear' has no HIP kernel yet (453 MMAC/sample GEMM + row dot); "
-                              "cross_attention / concat / add branches are implemented")
+    """nn.Bilinear fusion branch (reference vqa_model.py:348-351,404-415): y[b,o] = x1[b] W[o] x2[b] + bias[o]."""
+    _need_cuda(x1, 'bilinear')
+    D1, D2, Do = x1.shape[1], x2.shape[1], weight.shape[0]
+    if D2 % 8 or (D1 * D2) % 8 or Do % 8:
+        raise NotImplementedError(f'bilinear: dims must be multiples of 8 (got {D1}, {D2} -> {Do})')
+    y = _BilinearFn.apply(x1, x2, weight)
+    return y + bias if bias is not None else y
