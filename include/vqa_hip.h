@@ -154,7 +154,12 @@ typedef struct VqaAttnDesc {
      * sums over all B*S rows of the bf16 dq / dk / dv written above = the bias gradients of the Q/K/V projections, fused so
      * that no separate pass re-reads the three tensors. */
     float* dq_colsum; float* dk_colsum; float* dv_colsum;
+    /* optional, backward: workspace of vqa_attention_bwd_ws_floats(...) floats.  Needed (non-zero size) only when the tiles of one
+     * (batch, head) exceed the LDS together (Sq = Skv = 100 at Dh = 256: the ObjectDetection expert's queries): the backward then
+     * runs as two launches that hand the probabilities / dS over through it. */
+    float* ws;
 } VqaAttnDesc;
+size_t vqa_attention_bwd_ws_floats(int B, int H, int Sq, int Skv, int Dh);
 int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s);
 void vqa_set_attention_mfma(int on);       /* 1 (default): MFMA kernel for Sq,Skv <= 64, Dh in {32,64,96,128}; 0: generic kernel only */
 int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s);

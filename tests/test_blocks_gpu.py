@@ -165,6 +165,29 @@ def test_moe_layer(D, Hm, B, E):
     print('moe', D, B, 'out', rl(mg, mo), 'dx', rl(xg.grad, xo.grad), 'worst', check_grads(moe, lv, 'moe_layer.'))
 
 
+@pytest.mark.parametrize('D,Hm,B', [(64, 128, 3), (768, 2048, 4)])
+def test_object_detection_expert(D, Hm, B):
+    """ObjectDetectionExpert (reference specialized_experts.py:176-308; reachable from 8 experts): 100 learned queries through a
+    3-layer decoder, then the token attends over them.  At full size its attention backward (Sq = Skv = 100, Dh = 256) does not
+    fit the LDS in one piece: the generic kernel runs it as two launches through a workspace (include/vqa_hip.h)."""
+    from vqa_model_builder_amd.modeling.moe.experts import ObjectDetectionExpert
+    ex = ObjectDetectionExpert(input_dim=D, hidden_dim=Hm, output_dim=D, expert_id=0, dropout=0.1).eval()
+    sd = load_det(ex, 11, 'e.')
+    ex = ex.to(DEV)
+    x = dw.normal('x', (B, 1, D), 11)
+    lv = leaves_of(sd)
+    xo = x.clone().requires_grad_(True)
+    yo = vo.object_detection_expert(lv, 'e.', xo)
+    gy = dw.normal('gy', tuple(yo.shape), 11)
+    (yo * gy).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    yg = ex(xg)
+    (yg * gy.to(DEV)).sum().backward()
+    assert rl(yg, yo) <= OUT_TOL
+    assert rl(xg.grad, xo.grad) <= 2 * GRAD_TOL
+    print('detection expert', D, B, 'out', rl(yg, yo), 'dx', rl(xg.grad, xo.grad), 'worst', check_grads(ex, lv, 'e.', tol=2 * GRAD_TOL))
+
+
 @pytest.mark.parametrize('D,hidden,C,B', [(64, [48, 40], 37, 3), (768, [768, 512], 3000, 32)])
 def test_answer_head_and_loss(D, hidden, C, B):
     from vqa_model_builder_amd.hip import ops

@@ -177,7 +177,8 @@ def _ref_attn(q, k, v, B, H, Sq, Skv, Dh, mask):
 
 @pytest.mark.parametrize('B,H,Sq,Skv,Dh,masked', [(3, 4, 8, 8, 16, True), (2, 12, 50, 50, 64, False), (2, 12, 64, 64, 64, True),
                                                   (2, 8, 64, 50, 96, False), (3, 8, 4, 1, 256, False), (2, 8, 4, 4, 256, False),
-                                                  (2, 4, 17, 10, 16, True), (1, 2, 100, 128, 32, True)])
+                                                  (2, 4, 17, 10, 16, True), (1, 2, 100, 128, 32, True),
+                                                  (2, 8, 100, 100, 256, False), (2, 8, 100, 1, 256, False), (2, 8, 1, 100, 256, True)])
 def test_attention_fwd_bwd(B, H, Sq, Skv, Dh, masked):
     D = H * Dh
     # packed layouts with non-trivial leading dims: q in [.., 3D] at col 0, k/v in a [.., 2D] buffer

@@ -21,6 +21,10 @@ struct AttnArgs {
     const uint8_t* mask;
     float scale, drop_p, inv_keep;
     uint64_t seed; uint32_t stream;
+    // backward of shapes whose tiles do not fit the LDS together (Sq = Skv = 100, Dh = 256: the ObjectDetection expert's
+    // queries): mode 1 = phase A alone (K, V in LDS; q / dO rows from global; P', dS to the workspace), mode 2 = phase B alone
+    // (Q, dO in LDS; P', dS read back).  mode 0 = both phases in one launch, everything in LDS.
+    int mode; float* ws;
 };
 
 // orders this wave's own LDS writes before its following cross-lane LDS reads (per-wave scratch rows)
@@ -108,50 +112,69 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a_in) {
     if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pitch = a.Dh + 2, pp = a.Skv + 1;
+    const bool phaseA = a.mode != 2, phaseB = a.mode != 1;
+    // LDS: [K, V] (phase A) [Q, dO] (phase B or mode 0) [P', dS] (mode 0 only) [per-wave rows] (phase A)
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + a.Skv * pitch;
-    bf16_t* Qs = Vs + a.Skv * pitch;
-    bf16_t* Gs = Qs + a.Sq * pitch;                                    // dO
-    float* Ps = reinterpret_cast<float*>(Gs + a.Sq * pitch);           // [Sq][Skv+1] dropped probabilities
-    float* Ds = Ps + a.Sq * pp;                                        // [Sq][Skv+1] dS
-    float* qbuf = Ds + a.Sq * pp;                                      // [NW][Dh] fp32 q row
+    bf16_t* Vs = Ks + (phaseA ? a.Skv * pitch : 0);
+    bf16_t* Qs = Vs + (phaseA ? a.Skv * pitch : 0);
+    bf16_t* Gs = Qs + (a.mode != 1 ? a.Sq * pitch : 0);               // dO
+    float* Ps = reinterpret_cast<float*>(Gs + (a.mode != 1 ? a.Sq * pitch : 0));     // [Sq][Skv+1] dropped probabilities
+    float* Ds = Ps + (a.mode == 0 ? a.Sq * pp : 0);                    // [Sq][Skv+1] dS
+    float* qbuf = Ds + (a.mode == 0 ? a.Sq * pp : 0);                  // [NW][Dh] fp32 q row
     float* gbuf = qbuf + NW * a.Dh;                                    // [NW][Dh] fp32 dO row
     float* sbuf = gbuf + NW * a.Dh;                                    // [NW][128] ds row
+    if (a.mode != 0) {                                                 // P', dS live in the global workspace of this (b, h)
+        Ps = a.ws + (size_t)blockIdx.x * 2 * a.Sq * pp;
+        Ds = Ps + (size_t)a.Sq * pp;
+    }
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    load_tile(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * a.Dh, a.Skv, a.Dh, a.ldk, pitch, tid);
-    load_tile(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * a.Dh, a.Skv, a.Dh, a.ldv, pitch, tid);
-    load_tile(Qs, a.q + (size_t)b * a.Sq * a.ldq + h * a.Dh, a.Sq, a.Dh, a.ldq, pitch, tid);
-    load_tile(Gs, a.d_o + (size_t)b * a.Sq * a.ldd_o + h * a.Dh, a.Sq, a.Dh, a.ldd_o, pitch, tid);
-    __syncthreads();
-    float* qrow = qbuf + wave * a.Dh;
-    float* grow = gbuf + wave * a.Dh;
-    float* srow = sbuf + wave * 128;
-    // phase A: per query row -> P', dS (LDS) and dQ (global)
-    for (int qi = wave; qi < a.Sq; qi += NW) {
-        wave_sync();
-        for (int d = lane; d < a.Dh; d += 64) { qrow[d] = (float)Qs[qi * pitch + d]; grow[d] = (float)Gs[qi * pitch + d]; }
-        wave_sync();
-        float p0, p1, ks0, ks1;
-        row_softmax(a, qrow, Ks, pitch, b, h, qi, lane, p0, p1, ks0, ks1);
-        const int j0 = lane, j1 = lane + 64;
-        float dp0 = 0.f, dp1 = 0.f;
-        if (j0 < a.Skv) dp0 = dot_row(grow, Vs + j0 * pitch, a.Dh) * ks0;
-        if (j1 < a.Skv) dp1 = dot_row(grow, Vs + j1 * pitch, a.Dh) * ks1;
-        const float delta = wave_sum(p0 * dp0 + p1 * dp1);
-        const float ds0 = p0 * (dp0 - delta) * a.scale, ds1 = p1 * (dp1 - delta) * a.scale;
-        if (j0 < a.Skv) { Ps[qi * pp + j0] = p0 * ks0; Ds[qi * pp + j0] = ds0; }
-        if (j1 < a.Skv) { Ps[qi * pp + j1] = p1 * ks1; Ds[qi * pp + j1] = ds1; }
-        srow[j0] = ds0; srow[j1] = ds1;
-        wave_sync();
-        bf16_t* dqg = a.dq + ((size_t)b * a.Sq + qi) * a.lddq + h * a.Dh;
-        for (int d = lane; d < a.Dh; d += 64) {
-            float acc = 0.f;
-            for (int j = 0; j < a.Skv; ++j) acc += srow[j] * (float)Ks[j * pitch + d];
-            dqg[d] = (bf16_t)acc;
-        }
+    const bf16_t* qg0 = a.q + (size_t)b * a.Sq * a.ldq + h * a.Dh;
+    const bf16_t* gg0 = a.d_o + (size_t)b * a.Sq * a.ldd_o + h * a.Dh;
+    if (phaseA) {
+        load_tile(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * a.Dh, a.Skv, a.Dh, a.ldk, pitch, tid);
+        load_tile(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * a.Dh, a.Skv, a.Dh, a.ldv, pitch, tid);
+    }
+    if (a.mode != 1) {
+        load_tile(Qs, qg0, a.Sq, a.Dh, a.ldq, pitch, tid);
+        load_tile(Gs, gg0, a.Sq, a.Dh, a.ldd_o, pitch, tid);
     }
     __syncthreads();
+    if (phaseA) {
+        float* qrow = qbuf + wave * a.Dh;
+        float* grow = gbuf + wave * a.Dh;
+        float* srow = sbuf + wave * 128;
+        // phase A: per query row -> P', dS (LDS or workspace) and dQ (global)
+        for (int qi = wave; qi < a.Sq; qi += NW) {
+            wave_sync();
+            if (a.mode == 0) {
+                for (int d = lane; d < a.Dh; d += 64) { qrow[d] = (float)Qs[qi * pitch + d]; grow[d] = (float)Gs[qi * pitch + d]; }
+            } else {
+                for (int d = lane; d < a.Dh; d += 64) { qrow[d] = (float)qg0[(size_t)qi * a.ldq + d]; grow[d] = (float)gg0[(size_t)qi * a.ldd_o + d]; }
+            }
+            wave_sync();
+            float p0, p1, ks0, ks1;
+            row_softmax(a, qrow, Ks, pitch, b, h, qi, lane, p0, p1, ks0, ks1);
+            const int j0 = lane, j1 = lane + 64;
+            float dp0 = 0.f, dp1 = 0.f;
+            if (j0 < a.Skv) dp0 = dot_row(grow, Vs + j0 * pitch, a.Dh) * ks0;
+            if (j1 < a.Skv) dp1 = dot_row(grow, Vs + j1 * pitch, a.Dh) * ks1;
+            const float delta = wave_sum(p0 * dp0 + p1 * dp1);
+            const float ds0 = p0 * (dp0 - delta) * a.scale, ds1 = p1 * (dp1 - delta) * a.scale;
+            if (j0 < a.Skv) { Ps[qi * pp + j0] = p0 * ks0; Ds[qi * pp + j0] = ds0; }
+            if (j1 < a.Skv) { Ps[qi * pp + j1] = p1 * ks1; Ds[qi * pp + j1] = ds1; }
+            srow[j0] = ds0; srow[j1] = ds1;
+            wave_sync();
+            bf16_t* dqg = a.dq + ((size_t)b * a.Sq + qi) * a.lddq + h * a.Dh;
+            for (int d = lane; d < a.Dh; d += 64) {
+                float acc = 0.f;
+                for (int j = 0; j < a.Skv; ++j) acc += srow[j] * (float)Ks[j * pitch + d];
+                dqg[d] = (bf16_t)acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (!phaseB) return;
     // phase B: per key row -> dK, dV
     for (int j = wave; j < a.Skv; j += NW) {
         bf16_t* dkg = a.dk + ((size_t)b * a.Skv + j) * a.lddk + h * a.Dh;
@@ -183,6 +206,7 @@ int fill_args(const VqaAttnDesc* d, AttnArgs& a, bool bwd) {
     a.d_o = (const bf16_t*)d->d_o; a.ldd_o = d->ldd_o;
     a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
     a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
+    a.mode = 0; a.ws = nullptr;
     if (!bwd && !d->o) return VQA_ERR_ARG;
     if (bwd && (!d->d_o || !d->dq || !d->dk || !d->dv || (d->ldd_o % 2))) return VQA_ERR_ARG;
     return VQA_OK;
@@ -224,6 +248,13 @@ int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s) {
     return (int)hipGetLastError();
 }
 
+size_t vqa_attention_bwd_ws_floats(int B, int H, int Sq, int Skv, int Dh) {
+    const int pitch = Dh + 2, pp = Skv + 1;
+    const size_t lds = (size_t)2 * (Skv + Sq) * pitch * 2 + (size_t)2 * Sq * pp * 4 + (size_t)2 * NW * Dh * 4 + (size_t)NW * 128 * 4;
+    const bool mfma = g_attn_mfma && Sq <= 64 && Skv <= 64 && (Dh == 32 || Dh == 64 || Dh == 96 || Dh == 128);
+    return (mfma || lds <= LDS_MAX) ? 0 : (size_t)B * H * 2 * Sq * pp;
+}
+
 int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s) {
     if (g_attn_mfma && d && d->q && d->k && d->v && d->d_o && d->dq && d->dk && d->dv && d->B > 0 && d->H > 0) {
         const int rc = vqa_attention_mfma_bwd(d, (hipStream_t)s);
@@ -233,15 +264,31 @@ int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s) {
     int rc = fill_args(d, a, true);
     if (rc) return rc;
     const int pitch = a.Dh + 2, pp = a.Skv + 1;
-    const size_t lds = (size_t)2 * (a.Skv + a.Sq) * pitch * 2 + (size_t)2 * a.Sq * pp * 4 + (size_t)2 * NW * a.Dh * 4 + (size_t)NW * 128 * 4;
-    if (lds > LDS_MAX) return VQA_ERR_ARG;
+    const size_t rows_b = (size_t)2 * NW * a.Dh * 4 + (size_t)NW * 128 * 4;
+    const size_t lds = (size_t)2 * (a.Skv + a.Sq) * pitch * 2 + (size_t)2 * a.Sq * pp * 4 + rows_b;
     static size_t attr = 0;
-    if (lds > 64 * 1024 && lds > attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-        if (e != hipSuccess) return (int)e;
-        attr = LDS_MAX;
+    auto need = [&](size_t bytes) -> int {
+        if (bytes > 64 * 1024 && bytes > attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+            if (e != hipSuccess) return (int)e;
+            attr = LDS_MAX;
+        }
+        return 0;
+    };
+    if (lds <= LDS_MAX) {
+        if ((rc = need(lds))) return rc;
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(NT), lds, (hipStream_t)s, a);
+    } else {
+        // two launches with P', dS in the caller's workspace (vqa_attention_bwd_ws_floats): phase A keeps K, V in LDS, phase B Q, dO
+        const size_t ldsA = (size_t)2 * a.Skv * pitch * 2 + rows_b, ldsB = (size_t)2 * a.Sq * pitch * 2 + rows_b;
+        if (!d->ws || ldsA > LDS_MAX || ldsB > LDS_MAX) return VQA_ERR_ARG;
+        if ((rc = need(ldsA > ldsB ? ldsA : ldsB))) return rc;
+        a.ws = d->ws;
+        a.mode = 1;
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(NT), ldsA, (hipStream_t)s, a);
+        a.mode = 2;
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(NT), ldsB, (hipStream_t)s, a);
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B * a.H), dim3(NT), lds, (hipStream_t)s, a);
     rc = (int)hipGetLastError();
     // the generic kernel does not fuse the bias-gradient column sums: separate passes (outputs are zero on entry by contract)
     const int HD = d->H * d->Dh;

@@ -342,8 +342,11 @@ def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, ld
     d.d_o, d.ldd_o = _p(d_o), H * Dh
     d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = _p(dq), _p(dk), _p(dv), lddq, lddk, lddv
     d.dq_colsum, d.dk_colsum, d.dv_colsum = _p(dq_colsum), _p(dk_colsum), _p(dv_colsum)
+    nws = L().vqa_attention_bwd_ws_floats(B, H, Sq, Skv, Dh)
+    ws = torch.empty((nws,), dtype=F32, device=q.device) if nws else None
+    d.ws = _p(ws)
     _chk(L().vqa_attention_bwd(C.byref(d), _stream()), 'vqa_attention_bwd')
-    d.dq_colsum = d.dk_colsum = d.dv_colsum = None
+    d.dq_colsum = d.dk_colsum = d.dv_colsum = d.ws = None
 
 
 # ---- CLIP / RoBERTa front ends ------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ class VqaAttnDesc(C.Structure):
                 ('B', i32), ('H', i32), ('Sq', i32), ('Skv', i32), ('Dh', i32), ('key_padding_mask', vp),
                 ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32),
                 ('d_o', vp), ('ldd_o', i32), ('dq', vp), ('dk', vp), ('dv', vp),
-                ('lddq', i32), ('lddk', i32), ('lddv', i32), ('dq_colsum', vp), ('dk_colsum', vp), ('dv_colsum', vp)]
+                ('lddq', i32), ('lddk', i32), ('lddv', i32), ('dq_colsum', vp), ('dk_colsum', vp), ('dv_colsum', vp), ('ws', vp)]
 
 
 class VqaGemmGroupItem(C.Structure):
@@ -91,6 +91,7 @@ SIGNATURES = {
     'vqa_layernorm_reduce_grouped': (i32, [vp, i32, vp]),
     'vqa_outer_bf16': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'vqa_outer_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_attention_bwd_ws_floats': (u64, [i32, i32, i32, i32, i32]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
     'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, f32, vp]),
