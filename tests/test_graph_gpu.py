@@ -172,3 +172,42 @@ def test_moe_model_trains_under_a_replayed_graph():
             assert abs(x - y) <= 5e-2 * max(1.0, abs(x)), (ref, got)       # steep tiny-model trajectory: bf16-level differences grow a few % in six steps
     finally:
         blocks.disable_indirect_seeds()
+
+
+def test_replays_follow_the_batches_they_are_given():
+    """Two different batches (different images, token ids, padding, labels) fed alternately: the replayed graph copies each into
+    its static inputs, so it follows the same eager sequence -- nothing of the capture batch (masks, position ids, labels) is
+    baked in."""
+    from oracle import det_weights as dw
+    from oracle.gen_golden import TINY
+    from vqa_model_builder_amd.graph import GraphedTrainStep
+    from vqa_model_builder_amd.hip import blocks
+    try:
+        d = TINY
+        def mk(seed):
+            px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=d['vocab'], num_answers=d['num_answers'], seed=seed)
+            return dict(pixel_values=px.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
+        b1, b2 = mk(77), mk(91)
+        assert not torch.equal(b1['attention_mask'], b2['attention_mask']) or not torch.equal(b1['input_ids'], b2['input_ids'])
+        seq = [b1, b2, b1, b2, b2, b1, b2]                     # seq[2] is the warm-up step GraphedTrainStep runs on its capture batch
+        model, opt, _ = _setup(train=False)
+        ref = []
+        for b in seq:
+            opt.zero_grad(set_to_none=True)
+            o = model(**b); o.loss.backward(); opt.step(); ref.append(o.loss.item())
+        model, opt, _ = _setup(train=False)
+        warm = 2
+        pre = torch.cuda.Stream()                               # (not the legacy default stream: see GraphedTrainStep's docstring)
+        pre.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(pre):
+            for b in seq[:warm]:                               # same first two steps, eagerly
+                opt.zero_grad(set_to_none=True)
+                o = model(**b); o.loss.backward(); opt.step()
+        torch.cuda.current_stream().wait_stream(pre)
+        torch.cuda.synchronize()
+        gs = GraphedTrainStep(model, opt, b1, warmup=1)         # one eager step on b1 (= seq[2]), then the capture
+        got = [gs(b).item() for b in seq[warm + 1:]]
+        for x, y in zip(ref[warm + 1:], got):
+            assert abs(x - y) <= 1e-2 * max(1.0, abs(x)), (ref, got)
+    finally:
+        blocks.disable_indirect_seeds()

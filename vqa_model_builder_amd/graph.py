@@ -29,7 +29,11 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True):
-        """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).  ``loss_of(output)`` picks the
+        """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
+        Construct this BEFORE training the model eagerly on the default stream (or run such steps under
+        ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
+        first backward, and a node bound to the legacy default stream cannot be joined into a capture ("capturing stream has
+        unjoined work") -- the same rule as PyTorch's whole-network capture recipe; the warm-up here runs on a side stream.  ``loss_of(output)`` picks the
         scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer`` in NON-overlap mode.
         ``parallel_towers``: the vision encoder runs as a parallel branch of the graph (measured on MI355X, cfg2, B=32:
         13.7 -> 10.6 ms/step).  ``defer_wgrad``: the weight-gradient GEMMs of both encoders are issued (grouped) after
@@ -49,7 +53,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):                      # warm-up off the default stream (allocator pools, lazy tables, tile attributes)
-            for _ in range(max(1, warmup)):
+            for _ in range(max(1, warmup)):    # at least one eager step in the capture's own configuration (streams, dense MoE dispatch)
                 self._fwd_bwd()
                 if reducer is not None:
                     reducer.reduce()
