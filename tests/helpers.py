@@ -23,7 +23,7 @@ def build_model(meta):
     return VietnameseVQAModel(model_config_from_dims(meta['dims'], meta['fusion_type'], meta['num_experts']))
 
 
-def collect_from_workers(q, procs, n, timeout=180):
+def collect_from_workers(q, procs, n, timeout=120):
     """Reads ``n`` results from the multiprocessing queue ``q``; fails at once (instead of sitting out the queue timeout in
     silence) when a worker has exited with an error, and after ``timeout`` seconds overall."""
     import queue as _queue
