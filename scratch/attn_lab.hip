@@ -11,7 +11,7 @@
 //             dV^T = dO^T P, dK^T = Q^T dS need sums over all query rows: P^T / dS^T cross LDS once (bf16).
 // Probabilities are recomputed in backward (nothing but Q,K,V,O is ever in HBM); dropout masks come from the counter
 // RNG keyed by (b, h, q, kv) exactly as in the shape-generic kernel (attention.hip), which remains the fallback.
-#include "common.h"
+#include "../vqa_model_builder_amd/csrc/common.h"
 #include "vqa_hip.h"
 
 namespace {
@@ -25,6 +25,7 @@ struct MArgs {
     float scale, drop_p, inv_keep;
     uint64_t seed; uint32_t stream;
     float *dq_cs, *dk_cs, *dv_cs;       // optional bias-gradient accumulators [H*Dh]
+    unsigned long long* trace;
 };
 
 // column sums of one wave's 16 x 4 slab (lane (i, g) holds row i, columns 4g..4g+3 of the bf16 values it just stored):
@@ -103,7 +104,8 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
             s[t][r] = ok ? s[t][r] * a.scale : -INFINITY;
             m = fmaxf(m, s[t][r]);
         }
-    m = xor32_max(xor16_max(m));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -113,7 +115,8 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
             pn[t][r] = e;
             sum += e;
         }
-    sum = xor32_sum(xor16_sum(sum));
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     const int q = 16 * w + (lane & 15);
     const uint64_t base = (((uint64_t)b * a.H + h) * a.Sq + q) * (uint64_t)a.Skv;
@@ -184,11 +187,13 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
     const bool want_cs = a.dq_cs || a.dk_cs || a.dv_cs;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
+    unsigned long long tr[8]; tr[0] = __builtin_readcyclecounter();
     stage_tile<DH>(Qs, a.q + (size_t)b * a.Sq * a.ldq + h * DH, a.Sq, a.ldq, tid);
     stage_tile<DH>(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * DH, a.Skv, a.ldk, tid);
     stage_tile<DH>(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * DH, a.Skv, a.ldv, tid);
     stage_tile<DH>(Gs, a.d_o + (size_t)b * a.Sq * a.ldd_o + h * DH, a.Sq, a.ldd_o, tid);
     __syncthreads();
+    tr[1] = __builtin_readcyclecounter();
     // ---- phase 1: this wave's 16 query rows
     {
         f32x4 pn[4], ks[4], dp[4];
@@ -206,7 +211,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { dp[t][r] *= ks[t][r]; delta += pn[t][r] * dp[t][r]; }
-        delta = xor32_sum(xor16_sum(delta));
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
         const int q = 16 * w + i;
         const bool qok = q < a.Sq;
 #pragma unroll
@@ -237,7 +243,9 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
             if (want_cs) slab_colsum(&cs_part[0][w][16 * dt + 4 * g], ob, qok, lane);
         }
     }
+    tr[2] = __builtin_readcyclecounter();
     __syncthreads();
+    tr[3] = __builtin_readcyclecounter();
     // ---- phase 2: this wave's 16 key rows:  dV^T = dO^T P',  dK^T = Q^T dS   (k = q, natural order)
     const int kv = 16 * w + i;
     const bool kok = kv < a.Skv;
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
             slab_colsum(&cs_part[2][w][16 * dt + 4 * g], bv, kok, lane);
         }
     }
+    tr[4] = __builtin_readcyclecounter();
     if (want_cs) {
         __syncthreads();
         for (int c = tid; c < 3 * DH; c += 256) {
@@ -273,6 +282,9 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
             if (dst) atomicAdd(dst + h * DH + col, cs_part[which][0][col] + cs_part[which][1][col] + cs_part[which][2][col] + cs_part[which][3][col]);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tr[5] = __builtin_readcyclecounter();
+    if (a.trace && tid == 0) for (int k = 0; k < 6; ++k) a.trace[(size_t)blockIdx.x * 8 + k] = tr[k];
 }
 
 bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
@@ -291,6 +303,7 @@ bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
     a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)d->Dh);
     a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     a.seed = d->drop_seed; a.stream = d->drop_stream;
+    a.trace = nullptr;
     a.dq_cs = bwd ? d->dq_colsum : nullptr; a.dk_cs = bwd ? d->dk_colsum : nullptr; a.dv_cs = bwd ? d->dv_colsum : nullptr;
     return true;
 }
@@ -333,4 +346,11 @@ int vqa_attention_mfma_bwd(const VqaAttnDesc* d, hipStream_t s) {
         case 96: return launch_bwd<96>(a, s);
         default: return launch_bwd<128>(a, s);
     }
+}
+
+extern "C" int lab_attn_bwd(const VqaAttnDesc* d, unsigned long long* trace, void* stream) {
+    MArgs a;
+    if (!fill(d, a, true)) return -1;
+    a.trace = trace;
+    return launch_bwd<64>(a, (hipStream_t)stream);
 }

@@ -22,15 +22,47 @@ enum VqaAct { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3 }
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions.  __shfl_xor compiles to ds_bpermute_b32 on gfx950 -- an LDS-crossbar round trip of ~100 cycles per
+// step, and a reduction is a chain of them (measured: the bias-gradient column sums cost the attention backward 5000 cycles
+// per wave).  Inside a row of 16 lanes the DPP rotate does the same exchange in the VALU: row_ror by 8, 4, 2, 1 leaves the
+// row's sum (max) in all 16 lanes; the four row results of a wave are combined through v_readlane.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {          // every lane: sum over its row of 16 lanes
+    v += dpp_f32<0x128>(v); v += dpp_f32<0x124>(v); v += dpp_f32<0x122>(v); v += dpp_f32<0x121>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, dpp_f32<0x128>(v)); v = fmaxf(v, dpp_f32<0x124>(v)); v = fmaxf(v, dpp_f32<0x122>(v)); v = fmaxf(v, dpp_f32<0x121>(v));
     return v;
+}
+// Across rows gfx950 has v_permlane16_swap / v_permlane32_swap (VALU).  swap(a, b) returns {r0, r1}: in the even rows (lower
+// half) r0 keeps a and r1 receives the PARTNER's a; in the odd rows (upper half) r0 receives the partner's b and r1 keeps b
+// (probed on the device, scratch/lane_test).  With b = 0 resp. a = 0 the two calls give the partner's value on disjoint lanes.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ float xor16_partner(float v) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const u32x2_t p = __builtin_amdgcn_permlane16_swap(x, 0u, false, false), q = __builtin_amdgcn_permlane16_swap(0u, x, false, false);
+    return __builtin_bit_cast(float, p[1] | q[0]);
+}
+__device__ __forceinline__ float xor32_partner(float v) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const u32x2_t p = __builtin_amdgcn_permlane32_swap(x, 0u, false, false), q = __builtin_amdgcn_permlane32_swap(0u, x, false, false);
+    return __builtin_bit_cast(float, p[1] | q[0]);
+}
+__device__ __forceinline__ float xor16_sum(float v) { return v + xor16_partner(v); }
+__device__ __forceinline__ float xor32_sum(float v) { return v + xor32_partner(v); }
+__device__ __forceinline__ float xor16_max(float v) { return fmaxf(v, xor16_partner(v)); }
+__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, xor32_partner(v)); }
+__device__ __forceinline__ float lane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float wave_sum(float v) {            // every lane: sum over the 64 lanes
+    v = row_sum16(v);
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row_max16(v);
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 // Gauss error function pieces for the exact ("erf") GELU.  Abramowitz-Stegun 7.1.26: erf(z) = 1 - poly(t) exp(-z^2),

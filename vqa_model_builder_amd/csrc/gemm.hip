@@ -205,6 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     }
     constexpr int PITCH = EpiScratch<TN>::PITCH;
     constexpr int LPR = 4 * TN;                          // lanes per row after the turn
+    static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32, "column-sum fold handles these lane groups");
     constexpr int RPI = 64 / LPR;                        // rows per wave instruction
     static_assert(TM % G == 0, "strip group must divide the wave tile");
     const int wr_off = (lane & 15) * PITCH + (lane >> 4) * 16;
@@ -265,7 +266,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cs[r] += __shfl_xor(cs[r], o, 64);
+            for (int r = 0; r < 4; ++r)             // VALU lane exchanges (no ds_bpermute): rotations inside a 16-lane row keep l % LPR
+                cs[r] = o == 4 ? cs[r] + dpp_f32<0x124>(cs[r]) : o == 8 ? cs[r] + dpp_f32<0x128>(cs[r]) : o == 16 ? xor16_sum(cs[r]) : xor32_sum(cs[r]);
         }
         if (lane < LPR && nok) {
 #pragma unroll
