@@ -253,8 +253,12 @@ class CrossModalAttentionRunner:
         self.W, self.D, self.H, self.pd, self.eps = W, D, heads, dropout, eps
         self.arena = GradArena(W.params)
 
-    def forward(self, query, key_value, query_mask, kv_mask, training):
-        """query [B,Sq,D] fp32, key_value [B,Skv,D] fp32; masks bool [B,S] (True = ignore) or None."""
+    def forward(self, query, key_value, query_mask, kv_mask, training, first_only=False):
+        """query [B,Sq,D] fp32, key_value [B,Skv,D] fp32; masks bool [B,S] (True = ignore) or None.
+        ``first_only``: only output row 0 of every sample is wanted (the LAST fusion layer: MultimodalFusion reads token 0 and
+        nothing else, reference vqa_model.py:396-399) -> see forward_first."""
+        if first_only:
+            return self.forward_first(query, key_value, query_mask, kv_mask, training)
         W, D, H = self.W, self.D, self.H
         B, Sq, _ = query.shape
         Skv = key_value.shape[1]
@@ -287,6 +291,8 @@ class CrossModalAttentionRunner:
 
     def backward(self, saved, dout, need_dkv=True):
         """Returns (G, dquery [B,Sq,D] fp32, dkey_value [B,Skv,D] fp32 | None)."""
+        if saved.get('first'):
+            return self.backward_first(saved, dout, need_dkv)
         W, D, H = self.W, self.D, self.H
         S = saved
         B, Sq, Skv, seed, pd = S['B'], S['Sq'], S['Skv'], S['seed'], S['pd']
@@ -335,3 +341,100 @@ class CrossModalAttentionRunner:
         K.ln_reduce_flush()
         K.wgrad_join()
         return G, dx.view(B, Sq, D), dkv
+
+    # ---- the same block when only token 0 of the output is consumed -------------------------------------------------------
+    # Every row of this post-LN block depends on the other rows of ITS input only through the self-attention keys / values:
+    # with nothing but output row 0 read downstream, all other query rows are dead code, forward and backward (their upstream
+    # gradient is exactly zero in the reference too).  What remains: K|V projections over all text / vision rows, and the
+    # whole chain -- Q projections, both attentions (one query per sample), out-projections, LayerNorms, the FFN -- on B rows
+    # instead of B*Sq.  Outputs and every gradient are those of the full block (tests: golden parity of the whole model).
+    def forward_first(self, query, key_value, query_mask, kv_mask, training):
+        W, D, H = self.W, self.D, self.H
+        B, Sq, _ = query.shape
+        Skv = key_value.shape[1]
+        M, Mv, Dh, I = B * Sq, B * Skv, D // H, 4 * D
+        seed = new_seed() if training else 0
+        pd = self.pd if training else 0.0
+        x = query.reshape(M, D).contiguous().float()
+        xb = K.cast_bf16(x)
+        x0 = query[:, 0, :].contiguous().float()                        # [B, D]
+        x0b = K.cast_bf16(x0)
+        kvb = K.cast_bf16(key_value.reshape(Mv, D).contiguous().float())
+        qm, km = _mask_u8(query_mask), _mask_u8(kv_mask)
+        # --- self attention: one query (token 0) per sample over all text tokens
+        w_sa, b_sa = W.s('sa_in_w'), W.p('sa_in_b')
+        _, q0, _ = K.linear_fwd(x0b, w_sa[:D], b_sa[:D], B, D, D, want_bf16=True)
+        _, kvs, _ = K.linear_fwd(xb, w_sa[D:], b_sa[D:], M, 2 * D, D, want_bf16=True)
+        ctx = K.attention_fwd(q0, kvs[:, :D], kvs[:, D:], D, 2 * D, 2 * D, B, H, 1, Sq, Dh, qm, Drop(pd, seed, 1))
+        s1, _, _ = K.linear_fwd(ctx, W.s('sa_out_w'), W.p('sa_out_b'), B, D, D, want_f32=True, residual=x0, drop=Drop(pd, seed, 2))
+        x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p('n1.w'), W.p('n1.b'), B, D, want_bf16=True, eps=self.eps)
+        # --- cross attention
+        w_in, b_in = W.s('ca_in_w'), W.p('ca_in_b')
+        _, q2, _ = K.linear_fwd(x1b, w_in[:D], b_in[:D], B, D, D, want_bf16=True)
+        _, kv2, _ = K.linear_fwd(kvb, w_in[D:], b_in[D:], Mv, 2 * D, D, want_bf16=True)
+        ctx2 = K.attention_fwd(q2, kv2[:, :D], kv2[:, D:], D, 2 * D, 2 * D, B, H, 1, Skv, Dh, km, Drop(pd, seed, 3))
+        s2, _, _ = K.linear_fwd(ctx2, W.s('ca_out_w'), W.p('ca_out_b'), B, D, D, want_f32=True, residual=x1, drop=Drop(pd, seed, 4))
+        x2, x2b, m2, r2 = K.layernorm_fwd(s2, W.p('n2.w'), W.p('n2.b'), B, D, want_bf16=True, eps=self.eps)
+        # --- FFN
+        _, g, a = K.linear_fwd(x2b, W.s('ffn0_w'), W.p('ffn0_b'), B, I, D, want_bf16=True, want_pre=True, act=K.ACT_GELU, drop=Drop(pd, seed, 5))
+        s3, _, _ = K.linear_fwd(g, W.s('ffn3_w'), W.p('ffn3_b'), B, D, I, want_f32=True, residual=x2, drop=Drop(pd, seed, 6))
+        x3, _, m3, r3 = K.layernorm_fwd(s3, W.p('n3.w'), W.p('n3.b'), B, D, eps=self.eps)
+        saved = dict(first=True, B=B, Sq=Sq, Skv=Skv, seed=seed, pd=pd, qm=qm, km=km, xb=xb, x0b=x0b, kvb=kvb, q0=q0, kvs=kvs, ctx=ctx,
+                     s1=s1, m1=m1, r1=r1, x1b=x1b, q2=q2, kv2=kv2, ctx2=ctx2, s2=s2, m2=m2, r2=r2, x2b=x2b, a=a, g=g, s3=s3, m3=m3, r3=r3)
+        return x3.view(B, 1, D), saved
+
+    def backward_first(self, saved, dout, need_dkv=True):
+        W, D, H = self.W, self.D, self.H
+        S = saved
+        B, Sq, Skv, seed, pd = S['B'], S['Sq'], S['Skv'], S['seed'], S['pd']
+        M, Mv, Dh, I = B * Sq, B * Skv, D // H, 4 * D
+        dx3 = dout.reshape(B, D).contiguous().float()
+        dev = dx3.device
+        _, G = self.arena.alloc(dev)
+        ds3, ds3b, _, _ = K.layernorm_bwd(dx3, S['s3'], S['m3'], S['r3'], W.p('n3.w'), B, D, want_bf16=True, drop=Drop(pd, seed, 6), drop_mode=1,
+                                          dgamma=G['n3.w'], dbeta=G['n3.b'], dx_colsum=G['ffn3_b'], defer=True)
+        K.linear_dw(ds3b, S['g'], B, D, I, out=G['ffn3_w'], prezeroed=False)
+        _, da = K.linear_dx(ds3b, W.s('ffn3_w'), B, D, I, want_bf16=True, act_grad_of=S['a'], act_bwd=K.ACT_GELU, drop=Drop(pd, seed, 5),
+                            colsum=G['ffn0_b'])
+        K.linear_dw(da, S['x2b'], B, I, D, out=G['ffn0_w'], prezeroed=False)
+        dx2, _ = K.linear_dx(da, W.s('ffn0_w'), B, I, D, want_f32=True, residual=ds3)
+        # --- cross attention
+        ds2, ds2b, _, _ = K.layernorm_bwd(dx2, S['s2'], S['m2'], S['r2'], W.p('n2.w'), B, D, want_bf16=True, drop=Drop(pd, seed, 4), drop_mode=1,
+                                          dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'], defer=True)
+        K.linear_dw(ds2b, S['ctx2'], B, D, D, out=G['ca_out_w'], prezeroed=False)
+        _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), B, D, D, want_bf16=True)
+        dq2 = torch.empty((B, D), dtype=BF16, device=dev)
+        dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
+        kv2 = S['kv2']
+        K.attention_bwd(S['q2'], kv2[:, :D], kv2[:, D:], dctx2, D, 2 * D, 2 * D, B, H, 1, Skv, Dh, dq2, dkv2[:, :D], dkv2[:, D:],
+                        D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3),
+                        dq_colsum=G['ca_in_b'][:D], dk_colsum=G['ca_in_b'][D:2 * D], dv_colsum=G['ca_in_b'][2 * D:])
+        w_in = W.s('ca_in_w')
+        K.linear_dw(dq2, S['x1b'], B, D, D, out=G['ca_in_w'][:D], prezeroed=False)
+        dx1, _ = K.linear_dx(dq2, w_in[:D], B, D, D, want_f32=True, residual=ds2)
+        K.linear_dw(dkv2, S['kvb'], Mv, 2 * D, D, out=G['ca_in_w'][D:], prezeroed=False)
+        dkv = None
+        if need_dkv:
+            dkv, _ = K.linear_dx(dkv2, w_in[D:], Mv, 2 * D, D, want_f32=True)
+            dkv = dkv.view(B, Skv, D)
+        # --- self attention
+        ds1, ds1b, _, _ = K.layernorm_bwd(dx1, S['s1'], S['m1'], S['r1'], W.p('n1.w'), B, D, want_bf16=True, drop=Drop(pd, seed, 2), drop_mode=1,
+                                          dgamma=G['n1.w'], dbeta=G['n1.b'], dx_colsum=G['sa_out_b'], defer=True)
+        K.linear_dw(ds1b, S['ctx'], B, D, D, out=G['sa_out_w'], prezeroed=False)
+        _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), B, D, D, want_bf16=True)
+        kvs = S['kvs']
+        dq0 = torch.empty((B, D), dtype=BF16, device=dev)
+        dkvs = torch.empty((M, 2 * D), dtype=BF16, device=dev)
+        K.attention_bwd(S['q0'], kvs[:, :D], kvs[:, D:], dctx, D, 2 * D, 2 * D, B, H, 1, Sq, Dh, dq0, dkvs[:, :D], dkvs[:, D:],
+                        D, 2 * D, 2 * D, S['qm'], Drop(pd, seed, 1),
+                        dq_colsum=G['sa_in_b'][:D], dk_colsum=G['sa_in_b'][D:2 * D], dv_colsum=G['sa_in_b'][2 * D:])
+        w_sa = W.s('sa_in_w')
+        K.linear_dw(dq0, S['x0b'], B, D, D, out=G['sa_in_w'][:D], prezeroed=False)
+        K.linear_dw(dkvs, S['xb'], M, 2 * D, D, out=G['sa_in_w'][D:], prezeroed=False)
+        dx, _ = K.linear_dx(dkvs, w_sa[D:], M, 2 * D, D, want_f32=True)            # every text row: through the keys / values
+        dx0, _ = K.linear_dx(dq0, w_sa[:D], B, D, D, want_f32=True, residual=ds1)     # token 0: query path + residual stream
+        dx = dx.view(B, Sq, D)
+        dx[:, 0, :] += dx0
+        K.ln_reduce_flush()
+        K.wgrad_join()
+        return G, dx, dkv

@@ -217,23 +217,28 @@ class CrossModalAttention(nn.Module):
         self._runner = CrossModalAttentionRunner(W, D, num_heads, dropout)
         self._flat = _flatten_param_keys(W.params)
         self._masks = (None, None)
+        self._first_only = False
 
     def _hip_forward(self, query, key_value):
         self._W.shadows.refresh(query.device)
         qm, km = self._masks
-        return self._runner.forward(query, key_value, qm, km, self.training)
+        return self._runner.forward(query, key_value, qm, km, self.training, first_only=self._first_only)
 
     def _hip_backward(self, saved, dout, needs):
         G, dq, dkv = self._runner.backward(saved, dout, need_dkv=needs[1])
         return [dq if needs[0] else None, dkv], _split_grads(self._flat, G)
 
-    def forward(self, query, key_value, query_mask=None, kv_mask=None):
+    def forward(self, query, key_value, query_mask=None, kv_mask=None, first_token_only=False):
+        """``first_token_only`` (not in the reference signature): returns [B, 1, D] = row 0 of the block's output, computing only
+        what that row depends on (MultimodalFusion sets it for its last layer, whose other rows nobody reads)."""
         _require_cuda(query, 'CrossModalAttention')
         self._masks = (query_mask, kv_mask)
+        self._first_only = bool(first_token_only)
         try:
             return _BlockFn.apply(self, 2, query, key_value, *[p for _, p in self._flat])
         finally:
             self._masks = (None, None)
+            self._first_only = False
 
 
 class MultimodalFusion(nn.Module):
@@ -262,8 +267,10 @@ class MultimodalFusion(nn.Module):
     def forward(self, visual_features, text_features, visual_mask=None, text_mask=None):
         ft = self.config.fusion_type
         if ft == 'cross_attention':
-            for layer in self.fusion_layers:
-                text_features = layer(text_features, visual_features, text_mask, visual_mask)
+            last = len(self.fusion_layers) - 1
+            for i, layer in enumerate(self.fusion_layers):
+                # only token 0 of the last layer's output is read below: that layer computes just what token 0 depends on
+                text_features = layer(text_features, visual_features, text_mask, visual_mask, first_token_only=(i == last))
             fused = ops.linear(text_features[:, 0, :], self.output_proj.weight, self.output_proj.bias)
         elif ft == 'concat':
             combined = torch.cat([self._cls(visual_features), self._cls(text_features)], dim=-1)
