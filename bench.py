@@ -53,7 +53,7 @@ def build_model(workload, device):
     return model
 
 
-def make_optimizer(model, use_torch=False):
+def make_optimizer(model, use_torch=False, fp16=False):
     """Param groups of the reference loop (training_pipeline.py:239-252): no decay for bias / LayerNorm weights."""
     nd = ('bias', 'LayerNorm.weight', 'layer_norm.weight')
     decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(t in n for t in nd)]
@@ -62,7 +62,9 @@ def make_optimizer(model, use_torch=False):
     groups = [{'params': decay, 'weight_decay': 0.01}, {'params': no_decay, 'weight_decay': 0.0}]
     if use_torch:
         return torch.optim.AdamW(groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
-    return FusedAdamW(groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0).attach_shadows(model)
+    # fp16 operands: dynamic loss scale on the device (GradScaler's policy: reference training_pipeline.py:346-347,466-502)
+    return FusedAdamW(groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                      loss_scale='dynamic' if fp16 else None).attach_shadows(model)
 
 
 def synthetic_batch(B, device, rank):
@@ -136,13 +138,146 @@ def cpu_baseline(workload, steps=6, B=32, budget_s=30.0):
             'sample': f'{steps} timed steps (median) of batch {B}, fp32, eval-mode dropout-free oracle, fwd+bwd+clip+AdamW; {model_name}'}
 
 
+def run_workload(workload, args, device, world, rank, dist, want_roofline):
+    """Builds the model of ``workload``, captures / times the training step and (optionally) measures the GEMM roofline.
+    Returns a dict; frees everything it allocated."""
+    import gc
+    from vqa_model_builder_amd.hip import blocks as _blocks, kernels as K, lib
+    from vqa_model_builder_amd.dp import GradReducer
+    fp16 = args.dtype == 'fp16'
+    model = build_model(workload, device).train()
+    opt = make_optimizer(model, args.torch_optimizer, fp16)
+    params = [p for p in model.parameters() if p.requires_grad]
+    n_params = sum(p.numel() for p in params)
+    # the fused optimiser applies 1/world itself (grad_prescale): the all-reduced SUM is never rescaled in memory
+    reducer = GradReducer(params, average=args.torch_optimizer) if world > 1 else None
+    if world > 1 and not args.torch_optimizer:
+        opt.grad_prescale = 1.0 / world
+    px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        out = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
+        (opt.scale_loss(out.loss) if hasattr(opt, 'scale_loss') else out.loss).backward()
+        if reducer is not None:
+            reducer.finalize()
+        if args.torch_optimizer:
+            torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+        opt.step()                                   # FusedAdamW: global-norm clip (1.0) + AdamW + 16-bit shadow refresh, fused
+        return out.loss
+
+    # Single GPU: the whole step -- forward, backward, clip, AdamW -- is ONE captured HIP graph with the two encoders as parallel
+    # branches; every replay copies a batch into the static input buffers, draws fresh dropout masks (device-side RNG epoch)
+    # and advances the optimiser's device-side step count (and, fp16, its loss scale).
+    # N > 1: see vqa_model_builder_amd/graph.py (backward split into per-block graphs, each block's gradient arena all-reduced over
+    # RCCL on a side stream while the remaining backward replays; optimiser graph last).  Should the capture fail beside an
+    # initialised process group (the decision is all-or-nothing across ranks) every rank falls back to the eager step with the
+    # gradient exchange overlapped into backward by hooks.
+    use_graph = not args.eager and not args.torch_optimizer
+    step, launch, graphed = eager_step, 'eager', None
+    if use_graph:
+        from vqa_model_builder_amd.graph import GraphedTrainStep
+        batch = dict(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
+        ok = 1
+        try:
+            graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer,
+                                       capture_error_mode='thread_local' if world > 1 else 'global')
+        except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
+            ok = 0
+            print(f'[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); eager step', file=sys.stderr, flush=True)
+        if world > 1:
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            launch = graphed.describe() if hasattr(graphed, 'describe') else 'hip-graph'
+
+            def step():
+                return graphed(batch)
+    if launch == 'eager' and reducer is not None:
+        reducer.attach()                             # overlap: buckets go on the wire during backward
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    res = {'name': workload, 'workload': WORKLOADS[workload][2], 'ms_per_step': round(ms, 3), 'value': round(args.batch * world * args.steps / dt, 2),
+           'launch': launch, 'final_loss': round(float(loss), 4), 'params': n_params}
+    if fp16 and hasattr(opt, 'loss_scale'):
+        res['loss_scale'] = opt.loss_scale
+    if world > 1:
+        comm = graphed.comm_stats() if (graphed is not None and hasattr(graphed, 'comm_stats')) else {}
+        ranks = torch.ones(1, device=device)
+        dist.all_reduce(ranks)
+        res.update({'ranks_seen': int(ranks.item()), 'allreduce_bytes': reducer.bytes_per_step() if reducer is not None else 0, **comm})
+
+    if want_roofline:
+        # Instrumented re-run of the same step, one launch chain (each GEMM's own duration, not its share of an overlap).  Every
+        # launch of the MFMA GEMM family is issued through hipExtLaunchKernel with a start / stop event pair: the events carry the
+        # kernel's own begin / end timestamps from its dispatch packet -- the quantity rocprofv3 --kernel-trace reports -- with no
+        # host or event-record overhead inside the bracket.  Launches inside the fusion block (forward and backward) are tagged.
+        model.parallel_towers = False
+        L = lib.load()
+
+        def _tag(v):
+            def hook(*_a):
+                L.vqa_gemm_profile(1, v)
+            return hook
+        hooks = [model.fusion.register_forward_pre_hook(_tag(1)), model.fusion.register_forward_hook(_tag(0)),
+                 model.fusion.register_full_backward_pre_hook(_tag(1)), model.fusion.register_full_backward_hook(_tag(0))]
+        n_prof = 3
+        eager_step()                                  # settle allocator / shadows outside the graph
+        L.vqa_gemm_profile(1, 0)
+        for _ in range(n_prof):
+            eager_step()
+        torch.cuda.synchronize()
+        import ctypes as C
+        flop, msec, cnt = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int * 2)()
+        L.vqa_gemm_profile_collect(2, flop, msec, cnt)
+        L.vqa_gemm_profile(0, 0)
+        for h in hooks:
+            h.remove()
+        tot_flop, tot_ms, launches = (flop[0] + flop[1]) / n_prof, (msec[0] + msec[1]) / n_prof, (cnt[0] + cnt[1]) // n_prof
+        fus_flop, fus_ms = flop[1] / n_prof, msec[1] / n_prof
+        ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        fus = fus_flop / (fus_ms * 1e-3) / 1e12 if fus_ms > 0 else None
+        res['gemm'] = {'flop_per_step': tot_flop, 'ms_per_step': tot_ms, 'launches_per_step': launches, 'tflops': ach,
+                       'fusion_flop_per_step': fus_flop, 'fusion_ms_per_step': fus_ms, 'fusion_tflops': fus}
+    # free the workload (the next one builds its own model / graph pools)
+    del step, eager_step
+    graphed = opt = model = reducer = None
+    _blocks.disable_indirect_seeds()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--workload', default='cfg2_xattn', choices=list(WORKLOADS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'],
+                    help="16-bit type of the GEMM / attention operands: bf16 (default) or fp16 (+ dynamic loss scale), the reference loop's autocast dtype")
+    ap.add_argument('--no-second-workload', action='store_true',
+                    help='skip the MoE config (BASELINE configs[2]) that is otherwise timed too and reported as the "moe_config" object of the line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
@@ -168,137 +303,63 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    from vqa_model_builder_amd.hip import lib, kernels as K
+    import vqa_model_builder_amd as vqa
+    from vqa_model_builder_amd.hip import lib
     try:
-        lib.load()
+        vqa.set_compute_dtype(args.dtype)
     except lib.HipLibraryMissing:
         if rank == 0:
             import __graft_entry__
             __graft_entry__.build()
         if world > 1:
             dist.barrier()
-        lib.load()
-    from vqa_model_builder_amd.dp import GradReducer
+        vqa.set_compute_dtype(args.dtype)
 
-    model = build_model(args.workload, device).train()
-    opt = make_optimizer(model, args.torch_optimizer)
-    params = [p for p in model.parameters() if p.requires_grad]
-    # the fused optimiser applies 1/world itself (grad_prescale): the all-reduced SUM is never rescaled in memory
-    reducer = GradReducer(params, average=args.torch_optimizer) if world > 1 else None
-    if world > 1 and not args.torch_optimizer:
-        opt.grad_prescale = 1.0 / world
-    px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
-
-    def eager_step():
-        opt.zero_grad(set_to_none=True)
-        out = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
-        out.loss.backward()
-        if reducer is not None:
-            reducer.finalize()
-        if args.torch_optimizer:
-            torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
-        opt.step()                                   # FusedAdamW: global-norm clip (1.0) + AdamW + bf16 shadow refresh, fused
-        return out.loss
-
-    # Single GPU: the whole step -- forward, backward, clip, AdamW --
-    # is ONE captured HIP graph with the two encoders as parallel branches; every replay copies a batch into the static
-    # input buffers, draws fresh dropout masks (device-side RNG epoch) and advances the optimiser's device-side step count.
-    # N > 1: forward+backward is one graph, the bucketed RCCL all-reduce is launched eagerly between the replays (collectives
-    # stay outside the capture), the optimiser step is a second graph.  Should the capture fail beside an initialised process
-    # group (the capture decision is all-or-nothing across ranks) every rank falls back to the eager step with the
-    # gradient exchange overlapped into backward by hooks.
-    use_graph = not args.eager and not args.torch_optimizer
-    step = eager_step
-    launch = 'eager'
-    if use_graph:
-        from vqa_model_builder_amd.graph import GraphedTrainStep
-        batch = dict(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
-        ok = 1
+    main_res = run_workload(args.workload, args, device, world, rank, dist, want_roofline=not args.no_roofline)
+    moe_res = None
+    if not args.no_second_workload and args.workload != 'cfg3_mcan_moe4':
         try:
-            graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer,
-                                       capture_error_mode='thread_local' if world > 1 else 'global')
-        except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
-            ok = 0
-            print(f'[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); eager step', file=sys.stderr, flush=True)
-        if world > 1:
-            flag = torch.tensor([ok], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if ok:
-            launch = 'hip-graph (2 parallel encoder branches)' + ('; eager RCCL all-reduce between the backward and optimiser graphs' if world > 1 else '')
-
-            def step():
-                return graphed(batch)
-    if launch == 'eager' and reducer is not None:
-        reducer.attach()                             # overlap: buckets go on the wire during backward
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss)
-    ms = dt / args.steps * 1e3
-    value = args.batch * world * args.steps / dt
+            moe_res = run_workload('cfg3_mcan_moe4', args, device, world, rank, dist, want_roofline=False)
+        except Exception as e:                       # noqa: BLE001 -- the second object is a report, never a reason to lose the main number
+            moe_res = {'name': 'cfg3_mcan_moe4', 'error': f'{type(e).__name__}: {e}'}
 
     roofline = None
-    if not args.no_roofline:
-        # instrumented re-run of the same step: every launch of the MFMA GEMM kernel (the dominant kernel: >95 % of the
-        # path's FLOPs) is bracketed by HIP events on the stream it is launched on
-        model.parallel_towers = False                # one launch chain: each GEMM's own duration, not its share of an overlap
-        # GEMM launches inside the fusion block (forward and backward) are labelled: BASELINE's metric also names the MFMA
-        # utilisation of the cross-attention fusion
-        def _tag(v):
-            def hook(*_a):
-                K.PROFILE_TAG = v
-            return hook
-        hooks = [model.fusion.register_forward_pre_hook(_tag('fusion')), model.fusion.register_forward_hook(_tag('')),
-                 model.fusion.register_full_backward_pre_hook(_tag('fusion')), model.fusion.register_full_backward_hook(_tag(''))]
-        K.GEMM_PROFILE = []
-        eager_step()
-        eager_step()
-        torch.cuda.synchronize()
-        for h in hooks:
-            h.remove()
-        K.PROFILE_TAG = ''
-        prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
-        tot_flop = sum(p_[0] for p_ in prof)
-        tot_ms = sum(p_[1].elapsed_time(p_[2]) for p_ in prof)
-        fus_flop = sum(p_[0] for p_ in prof if p_[3] == 'fusion')
-        fus_ms = sum(p_[1].elapsed_time(p_[2]) for p_ in prof if p_[3] == 'fusion')
-        fus = fus_flop / (fus_ms * 1e-3) / 1e12 if fus_ms > 0 else None
-        ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process; they were collected with
-        # rocprofv3 on this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) and committed
+    if 'gemm' in main_res:
+        g = main_res.pop('gemm')
+        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process; they are collected with
+        # rocprofv3 on this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) by
+        # profiles/pmc_traffic.py and committed with their raw counter CSVs
         traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'gemm_traffic.json')))
-            if args.workload == 'cfg2_xattn' and args.batch == 32:
-                traffic, traffic_src = tj['hbm_bytes_per_gemm_launch'], 'profiles/r01/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)'
-        except Exception:
-            pass
-        roofline = {'bound': 'mfma', 'kernel': 'gemm_v1_kernel / gemm_v1_grouped_kernel (all MFMA GEMM launches of a step)', 'achieved': round(ach, 2),
-                    'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                    'traffic_unit': 'B/launch (HBM side)', 'traffic_source': traffic_src,
-                    'launches_per_step': len(prof) // 2, 'gemm_ms_per_step': round(tot_ms / 2, 3),
-                    'fusion_gemm_tflops': None if fus is None else round(fus, 2),
-                    'fusion_mfma_util': None if fus is None else round(fus / PEAK_BF16_TFLOPS, 4),
-                    'fusion_gemm_ms_per_step': round(fus_ms / 2, 3),
-                    'gemm_gflop_per_step': round(tot_flop / 2 / 1e9, 1),
-                    'whole_step_tflops': round(GFLOP_PER_SAMPLE[args.workload] * args.batch / (ms * 1e-3) / 1e3, 2)}
+        for rnd in ('r02', 'r01'):
+            try:
+                tj = json.load(open(os.path.join(REPO, 'profiles', rnd, 'gemm_traffic.json')))
+                if args.workload == 'cfg2_xattn' and args.batch == 32:
+                    traffic = tj['hbm_bytes_per_gemm_launch']
+                    traffic_src = f'profiles/{rnd}/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)'
+                break
+            except Exception:
+                continue
+        ms = main_res['ms_per_step']
+        roofline = {'bound': 'mfma', 'kernel': 'gemm_v1_kernel / gemm_v1_grouped_kernel (all MFMA GEMM launches of a step)',
+                    'achieved': round(g['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(g['tflops'] / PEAK_BF16_TFLOPS, 4),
+                    'timing': 'kernel begin/end timestamps of every GEMM dispatch (hipExtLaunchKernel start/stop events) = what rocprofv3 --kernel-trace reports',
+                    'traffic': traffic, 'traffic_unit': 'B/launch (HBM side)', 'traffic_source': traffic_src,
+                    'launches_per_step': g['launches_per_step'], 'gemm_ms_per_step': round(g['ms_per_step'], 3),
+                    'gemm_gflop_per_step': round(g['flop_per_step'] / 1e9, 1),
+                    'fusion_gemm_tflops': None if g['fusion_tflops'] is None else round(g['fusion_tflops'], 2),
+                    'fusion_mfma_util': None if g['fusion_tflops'] is None else round(g['fusion_tflops'] / PEAK_BF16_TFLOPS, 4),
+                    'fusion_gemm_ms_per_step': round(g['fusion_ms_per_step'], 3),
+                    # launched FLOPs (the dead rows of the last fusion layer are not executed and not credited) over the whole step
+                    'whole_step_tflops': round(g['flop_per_step'] / (ms * 1e-3) / 1e12, 2)}
+    if moe_res is not None and 'ms_per_step' in moe_res:
+        # the MoE config is bound by HBM bytes that do not depend on the batch: 16-bit weights read forward and backward (2 x 2 B),
+        # fp32 gradients written (4 B), AdamW + shadow refresh (30 B) per parameter -- SURVEY section 8(d)
+        P = moe_res['params']
+        byts = (2 * 2 + 4 + 30) * P
+        gbs = byts / (moe_res['ms_per_step'] * 1e-3) / 1e9
+        moe_res['roofline'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+                               'bytes_per_step': byts, 'traffic': None,
+                               'note': 'whole step against the batch-independent parameter traffic (4 + 4 + 30 B/param); activations excluded'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -309,15 +370,15 @@ def main():
 
     if rank == 0:
         line = {
-            'metric': 'train samples/sec (img+question)', 'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': WORKLOADS[args.workload][2], 'name': args.workload, 'batch_per_gpu': args.batch,
+            'metric': 'train samples/sec (img+question)', 'value': main_res['value'], 'unit': 'samples/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': main_res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': main_res['workload'], 'name': args.workload, 'batch_per_gpu': args.batch,
                        'global_batch': args.batch * world, 'image': '3x224x224', 'seq_len': 64,
                        'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
-                       'launch': launch,
-                       'final_loss': round(final_loss, 4)},
-            'roofline': roofline, 'cpu_baseline': cpu,
+                       'launch': main_res['launch'], 'final_loss': main_res['final_loss'],
+                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'exposed_comm_ms', 'comm_ms', 'predicted_8gpu_ms') if k in main_res}},
+            'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

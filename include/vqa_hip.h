@@ -30,6 +30,10 @@ typedef void* vqa_stream_t;
 #define VQA_ACT_RELU 3        /* vqa_model.py:343,458 */
 
 int vqa_abi_version(void);
+/* 0: this library was built with bfloat16 GEMM / attention operands (libvqa_hip.so), 1: IEEE fp16 (libvqa_hip_f16.so, the dtype
+ * of the reference's main loop: autocast fp16 + GradScaler, training_pipeline.py:346-347,457).  Same sources, same entry
+ * points: every "bf16" in a name or field below means "the library's 16-bit operand type". */
+int vqa_half_kind(void);
 
 /* ---- GEMM: C[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)) ------------------------------------------------
  * Replaces every nn.Linear / packed in_proj on the path (torch F.linear; e.g. vqa_model.py:266-269,338,457,
@@ -51,7 +55,8 @@ typedef struct VqaGemmDesc {
     float drop_p; uint64_t drop_seed; uint32_t drop_stream;   /* inverted dropout on the output, index m*N+n */
     int split_k;                           /* 0 = auto (only if allow_split_k), 1 = off, >1 forced */
     int allow_split_k;                     /* fp32 atomics into c_f32 (zeroed here); plain fp32 output only */
-    int tile_hint;                         /* 0 auto; 1:128x128 2:64x64 3:32x128 4:128x32 5:128x64 6:64x128 */
+    int tile_hint;                         /* 0 auto; else 1 + tile id of csrc/gemm.hip: 1:128x128 2:64x64 3:32x128 4:128x32 5:128x64 6:64x128
+                                              7:256x128 (8 waves) 8:32x32 9:32x64 */
     float* colsum;                         /* optional fp32 [N], PRE-ZEROED by the caller: += column sums of the output values
                                               (after bias/act'/dropout, before the residual): the bias gradient of the producer */
     int c_prezeroed;                       /* split-K only: c_f32 is already zero, skip the memset */
@@ -67,11 +72,17 @@ typedef struct VqaGemmGroupItem {
     int M, N, K, lda, ldb, ldc;
 } VqaGemmGroupItem;
 int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);   /* a_kc == b_kc */
+/* Measurement (bench.py): while on, every GEMM dispatch carries a start / stop event pair that receives the kernel's own begin /
+ * end timestamps (hipExtLaunchKernel) -- the durations rocprofv3 --kernel-trace reports; `tag` labels the launches that follow.
+ * vqa_gemm_profile_collect waits for the recorded launches and returns, per tag < ntags, their summed 2*M*N*K FLOP, kernel
+ * milliseconds and count, then forgets them.  Host-side state only; not for use inside a stream capture. */
+void vqa_gemm_profile(int on, int tag);
+int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches);
 void vqa_set_gemm_grid_cap(int cap);      /* > 0: LDS-DMA GEMMs run persistent on at most `cap` workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_force(int cfg, int stages);   /* diagnostics: tile id (0: 128x128, 1: 64x64, 4: 128x64, 5: 64x128; -1: heuristics) for every LDS-DMA launch */
 void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
-void vqa_set_gemm_group_m(int g);          /* tile-row group of the L2-aware tile order (default 16; <= 1 = row-major) */
+void vqa_set_gemm_group_m(int g);          /* tile-row group of the L2-aware tile order (default 1 = row-major inside the XCD ranges) */
 void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */
 
 /* ---- elementwise / layout --------------------------------------------------------------------------------- */
@@ -165,20 +176,25 @@ void vqa_set_attention_mfma(int on);       /* 1 (default): MFMA kernel for Sq,Sk
 int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s);
 
 /* ---- RoBERTa embeddings (HF RobertaEmbeddings: word + type0 + pad-aware positions, LN) --------------------- */
-/* pos_ids out: int32 [B,S] = cumsum(ids != pad) * (ids != pad) + pad.  u = sum of the three rows (fp32). */
+/* pos_ids out: int32 [B,S] = cumsum(ids != pad) * (ids != pad) + pad.  u = sum of the three rows (fp32).
+ * V / Pmax: rows of the word / position tables.  An id outside [0,V) or a position id >= Pmax (nn.Embedding: error) is never
+ * dereferenced -- the padding row is read instead -- and *ok (optional device int32, initialised to 1 by the caller) is cleared. */
 int vqa_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
-                          int32_t* pos_ids, float* u, int B, int S, int D, int pad_id, vqa_stream_t s);
+                          int32_t* pos_ids, float* u, int B, int S, int D, int pad_id, int V, int Pmax, int32_t* ok, vqa_stream_t s);
 /* scatter-add du into dword/dpos (rows pad_id skipped: nn.Embedding padding_idx) and dtype0 = sum of all rows.
  * dword [V,D] and dpos [Pmax,D] must be zero-filled by the caller; dtype0 [D]. */
 int vqa_roberta_embed_bwd(const float* du, const int64_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
-                          float* dtype0, int B, int S, int D, int pad_id, vqa_stream_t s);
+                          float* dtype0, int B, int S, int D, int pad_id, int V, int Pmax, vqa_stream_t s);
 
 /* ---- loss (vqa_model.py:711-716: F.cross_entropy mean + argmax) ------------------------------------------- */
-/* per-row loss (fp32 [B]) and argmax (int64 [B]); loss_mean (fp32 [1]) = mean over rows. */
+/* per-row loss (fp32 [B]) and argmax (int64 [B]); loss_mean (fp32 [2]) = {mean over the rows whose label is not
+ * ignore_index (-100, as F.cross_entropy), number of such rows}.  A label outside [0,C) other than -100 (torch: device assert)
+ * is never dereferenced: that row's loss is NaN and *ok (optional device int32, caller-initialised to 1) is cleared. */
 int vqa_softmax_ce_argmax_fwd(const float* logits, int ld, const int64_t* labels, float* row_loss, float* loss_mean,
-                              int64_t* argmax, float* lse, int B, int C, vqa_stream_t s);
-/* dlogits = (softmax - onehot) * (*dloss) / B ; outputs fp32 and optional bf16 copy */
-int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss,
+                              int64_t* argmax, float* lse, int B, int C, int32_t* ok, vqa_stream_t s);
+/* dlogits = (softmax - onehot) * (*dloss) / nvalid (rows with an ignored / invalid label: 0); nvalid = &loss_mean[1] of the forward
+ * (NULL: B); outputs fp32 and optional 16-bit copy */
+int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss, const float* nvalid,
                        float* dlogits, void* dlogits_bf16, int B, int C, vqa_stream_t s);
 
 /* ---- MoE router + dispatch (router.py:287-366, moe_layer.py:146-168); fp32 throughout ----------------------- */
@@ -242,9 +258,16 @@ int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
  * step on the device), so a captured HIP graph of the optimiser step follows the schedule and the step count. */
 int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
                     float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* hyper_dev,
-                    float grad_prescale, vqa_stream_t s);
+                    float grad_prescale, const float* amp_dev, vqa_stream_t s);
 /* grad_prescale (0 => 1): the gradients in memory are to be read as grad * grad_prescale (norm2 is of the UNscaled values):
  * data-parallel ranks hand over the all-reduced SUM and 1/world here, so the mean is never written out. */
+/* amp_dev (optional; needs norm2): device floats {loss_scale, growth_tracker, found_inf}: the gradients in memory are
+ * loss_scale x the true ones (fp16 mode; torch.amp.GradScaler's role, reference training_pipeline.py:346-347,466-502): they are
+ * un-scaled on the fly, and a non-finite norm2 (any inf / nan gradient) SKIPS the whole update like GradScaler.step() does.
+ * vqa_amp_update then applies GradScaler.update(): scale *= backoff_factor after a skipped step, *= growth_factor after
+ * growth_interval clean ones.  vqa_opt_advance: hyper_dev[1] (the device step count) += 1 unless norm2 is non-finite. */
+int vqa_amp_update(float* amp_dev, const float* norm2, float growth_factor, float backoff_factor, int growth_interval, vqa_stream_t s);
+int vqa_opt_advance(float* hyper_dev, const float* norm2, vqa_stream_t s);
 /* nn.Bilinear (fusion_type='bilinear', vqa_model.py:348-351): y = z W^T with z[b, i*D2+j] = x1[b,i]*x2[b,j] (bf16, one GEMM over
  * K = D1*D2) -- vqa_outer_bf16 builds z; vqa_outer_bwd contracts dz = dy W back: dx1[b,i] = <dz[b,i,:], x2[b]>, dx2[b,j] =
  * sum_i dz[b,i,j] x1[b,i].  D2 % 4 == 0. */

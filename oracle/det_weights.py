@@ -89,6 +89,28 @@ def make_inputs(batch: int, seq_len: int = 64, image_size: int = 224, vocab_hi: 
     return px, ids, mask, labels
 
 
+def make_input_pool(n: int, seq_len: int = 64, image_size: int = 224, vocab_hi: int = 30000, num_answers: int = 3000,
+                    seed: int = 0):
+    """A pool of ``n`` candidate samples for the batch-32 fixtures: ``oracle/gen_golden.py`` keeps the candidates whose
+    top-1/top-2 logit margin in the REFERENCE is far above any 16-bit rounding error (and, with a MoE, whose top-k expert
+    choice is not a numerical tie) and records their indices in the fixture; tests rebuild the pool from the seed and take
+    the same rows.  Every sixth row is right-padded (mask 0 + pad id 1, varying lengths), another sixth carries a stray
+    attended ``input_ids == 1`` (shifts the RoBERTa position ids)."""
+    px = normal('pool.pixel_values', (n, 3, image_size, image_size), seed)
+    ids = randint('pool.input_ids', (n, seq_len), 0, vocab_hi, seed)
+    ids[ids == 1] = 2
+    mask = torch.ones(n, seq_len, dtype=torch.int64)
+    for r in range(n):
+        if r % 6 == 1:
+            cut = max(2, (seq_len * (3 + (r // 6) % 4)) // 8)
+            ids[r, cut:] = 1
+            mask[r, cut:] = 0
+        elif r % 6 == 4:
+            ids[r, min(3 + r % 5, seq_len - 1)] = 1
+    labels = randint('pool.labels', (n,), 0, num_answers, seed)
+    return px, ids, mask, labels
+
+
 def checksum(state_dict: Dict[str, torch.Tensor], names: Iterable[str] = None) -> float:
     """Order-independent fp64 digest used by fixtures to detect generator drift."""
     tot = 0.0

@@ -1,7 +1,7 @@
 """Golden-vector generator.  Runs ONLY in the build container, where /root/reference is importable.
 
     mkdir -p /tmp/golden_cwd && cd /tmp/golden_cwd && \
-    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|parts]
+    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts]
 
 It imports the reference's own ``src.modeling.meta_arch`` / ``src.modeling.moe`` modules (SURVEY.md
 §8c, Appendix C), replaces only the two hub-NAME loaders by local random-weight construction of the
@@ -90,7 +90,7 @@ class _RoundBF16(torch.autograd.Function):
         return g.bfloat16().float()
 
 
-def bf16_envelope(sd, cfg, px, ids, mask, labels, dims):
+def bf16_envelope(sd, cfg, px, ids, mask, labels, dims, grad_names):
     """What bf16 GEMM operands with fp32 accumulation cost, measured on the (reference-pinned) CPU oracle itself:
     every linear / matmul / conv operand is rounded to bf16, everything else stays fp32.  The HIP path uses exactly
     this numeric scheme, so these deviations from the fp32 result are the floor any bf16 implementation (torch
@@ -109,19 +109,87 @@ def bf16_envelope(sd, cfg, px, ids, mask, labels, dims):
         F.linear, torch.matmul, F.conv2d = ol, om, oc
     rl = lambda a, b: float((a - b).double().norm() / (b.double().norm() + 1e-30))
     out = {'emul/logits_rel_l2': np.float64(rl(l1, l0)), 'emul/logits_max_abs': np.float64(float((l1 - l0).abs().max()))}
-    for k in g0:
-        if k in g1:
-            out['emul/g/' + k] = np.float64(rl(g1[k], g0[k]))
+    out['emul/g'] = np.array([rl(g1[k], g0[k]) if (k in g0 and k in g1) else np.nan for k in grad_names], dtype=np.float64)
     return out
 
 
-def run_model_case(tag, dims, fusion_type, num_experts, seed, full_grads):
+AC_MODES = (('ac_bf16', torch.bfloat16, 1.0), ('ac_fp16', torch.float16, 1024.0))
+
+
+def autocast_envelope(model, px, ids, mask, labels, logits0, grads0, rich):
+    """The REFERENCE ITSELF under ``torch.autocast`` -- the context its training loops run the model in
+    (reference src/core/training_pipeline.py:457 fp16 + GradScaler; src/pipeline/trainer/vqa_trainer.py:760-764 fp16|bf16) --
+    compared with its own fp32 result on the same weights and inputs.  (The old operand-rounding emulation inside our own oracle, ``bf16_envelope``, is kept as an
+    informative second number only.)  This is what "the reference at 16-bit operand
+    precision" deviates from "the reference at fp32" by: the tolerance the HIP path is held to comes from these numbers,
+    not from any emulation of ours.  fp16 runs with a fixed loss scale of 1024 (GradScaler's role; gradients unscaled
+    before the comparison).  Stored per mode: logits rel-L2 / max-abs, answer ids, and per parameter the rel-L2 error of the
+    whole gradient (``/g``) and of the fixture's sample of it (``/gs``, what the GPU test can compare), as vectors in the order
+    of the fixture's ``grad_names``."""
+    rl = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    out = {}
+    for tag, dt, scale in AC_MODES:
+        model.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            with torch.autocast('cpu', dtype=dt):
+                o = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
+            (o.loss.float() * scale).backward()
+        l1 = o.logits.detach().float()
+        out[tag + '/logits_rel_l2'] = np.float64(rl(l1, logits0))
+        out[tag + '/logits_max_abs'] = np.float64(float((l1 - logits0).abs().max()))
+        out[tag + '/predictions'] = l1.argmax(-1).numpy()
+        named = dict(model.named_parameters())
+        gfull, gsamp = [], []
+        for name in grads0:                                   # order = meta['grad_names']
+            g1 = named[name].grad.detach().float() / scale
+            gfull.append(rl(g1, grads0[name]))
+            gsamp.append(rl(sample_grad(g1, rich), sample_grad(grads0[name], rich)))
+        out[tag + '/g'] = np.array(gfull, dtype=np.float64)   # per parameter, whole gradient
+        out[tag + '/gs'] = np.array(gsamp, dtype=np.float64)  # per parameter, on the fixture's sample of it
+    model.zero_grad(set_to_none=True)
+    return out
+
+
+def select_samples(model, dims, num_experts, seed, n_cand, n_keep):
+    """Rows of ``det_weights.make_input_pool`` kept for a batch-32 fixture: the candidates with the LARGEST top-1/top-2
+    logit margin in the reference (argmax ids can then be gated bit-exact on every sample: the margins end up an order of
+    magnitude above the 16-bit logit error), excluding -- with a MoE -- samples whose k-th / (k+1)-th router probabilities
+    are closer than 0.02 (a discrete expert choice that 16-bit rounding could flip).  Samples are independent in eval mode,
+    so selecting rows changes nothing about any row's expected output."""
+    px, ids, mask, labels = dw.make_input_pool(n_cand, dims['seq'], dims['image'], vocab_hi=min(30000, dims['vocab']),
+                                               num_answers=dims['num_answers'], seed=seed)
+    margins, gaps = [], []
+    with torch.no_grad():
+        for i0 in range(0, n_cand, 32):
+            sl = slice(i0, min(n_cand, i0 + 32))
+            o = model(pixel_values=px[sl], input_ids=ids[sl], attention_mask=mask[sl])
+            t2 = o.logits.topk(2, dim=-1).values
+            margins.append(t2[:, 0] - t2[:, 1])
+            if num_experts > 0:
+                pr = model.moe_layer.aux_outputs['router_probs'].reshape(t2.shape[0], -1).sort(dim=-1, descending=True).values
+                gaps.append(pr[:, 1] - pr[:, 2])
+    margins = torch.cat(margins)
+    ok = torch.ones(n_cand, dtype=torch.bool) if not gaps else torch.cat(gaps) > 0.02
+    score = torch.where(ok, margins, torch.full_like(margins, -1.0))
+    idx = torch.sort(score.topk(n_keep).indices).values
+    assert bool(ok[idx].all())
+    assert int((mask[idx].sum(1) < dims['seq']).sum()) >= 2, 'selection lost the padded rows'
+    print(f'[gen_golden] selected {n_keep}/{n_cand}: min margin {float(margins[idx].min()):.3f} (pool median {float(margins.median()):.3f}), '
+          f'{int((mask[idx].sum(1) < dims["seq"]).sum())} padded rows, {int((ids[idx] == 1).any(1).sum())} rows with pad ids')
+    return idx, (px[idx], ids[idx], mask[idx], labels[idx])
+
+
+def run_model_case(tag, dims, fusion_type, num_experts, seed, full_grads, pool=None, emulate=True):
     model, cfg = build_reference_model(dims, fusion_type, num_experts)
     shapes = dw.shapes_of(model.state_dict())
     sd = dw.make_state_dict(shapes, seed)
     model.load_state_dict(sd)
-    px, ids, mask, labels = dw.make_inputs(dims['batch'], dims['seq'], dims['image'],
-                                           vocab_hi=min(30000, dims['vocab']), num_answers=dims['num_answers'], seed=seed)
+    sel = None
+    if pool is None:
+        px, ids, mask, labels = dw.make_inputs(dims['batch'], dims['seq'], dims['image'],
+                                               vocab_hi=min(30000, dims['vocab']), num_answers=dims['num_answers'], seed=seed)
+    else:
+        sel, (px, ids, mask, labels) = select_samples(model, dims, num_experts, seed, pool, dims['batch'])
     with torch.enable_grad():
         out = model(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels, return_features=True)
         out.loss.backward()
@@ -146,17 +214,33 @@ def run_model_case(tag, dims, fusion_type, num_experts, seed, full_grads):
         arrays['router_probs'] = aux['router_probs'].detach().numpy()
         arrays['load_balance_loss'] = aux['load_balance_loss'].detach().numpy()
     from tests.conftest import CfgView
-    env = bf16_envelope(sd, CfgView(dict(dims=dims, fusion_type=fusion_type, num_experts=num_experts)), px, ids, mask, labels, dims)
-    arrays.update(env)
-    meta = dict(tag=tag, dims=dims, fusion_type=fusion_type, num_experts=num_experts, seed=seed,
+    grads0 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    ac = autocast_envelope(model, px, ids, mask, labels, out.logits.detach().clone(), grads0, full_grads)
+    arrays.update(ac)
+    env = {}
+    if emulate:
+        env = bf16_envelope(sd, CfgView(dict(dims=dims, fusion_type=fusion_type, num_experts=num_experts)), px, ids, mask, labels, dims, grad_names)
+        arrays.update(env)
+    if sel is not None:
+        arrays['pool_index'] = sel.numpy()
+    for mode, _, _ in AC_MODES:
+        gn = dict(zip(grad_names, ac[mode + '/g'].tolist()))
+        num = sum((gn[n] * float(arrays['gnorm/' + n])) ** 2 for n in gn)
+        den = sum(float(arrays['gnorm/' + n]) ** 2 for n in gn)
+        worst = max(gn.items(), key=lambda kv: kv[1] if float(arrays['gnorm/' + kv[0]]) > 1e-4 * max(float(arrays['gnorm/' + n]) for n in gn) else 0.0)
+        print(f'[gen_golden] {tag}: reference under autocast {mode[3:]}: logits rel-L2 {float(ac[mode + "/logits_rel_l2"]):.2e} max-abs '
+              f'{float(ac[mode + "/logits_max_abs"]):.2e}, answer ids kept {int((ac[mode + "/predictions"] == arrays["predictions"]).sum())}/{len(arrays["predictions"])}, '
+              f'gradients aggregate {np.sqrt(num / den):.2e} worst {worst[1]:.2e} ({worst[0]})')
+    meta = dict(tag=tag, dims=dims, fusion_type=fusion_type, num_experts=num_experts, seed=seed, pool=pool,
                 full_grads=full_grads, shapes={k: list(v) for k, v in shapes.items()},
                 grad_names=grad_names, none_grad_names=none_names, weights_checksum=dw.checksum(sd),
                 torch=torch.__version__, transformers=__import__('transformers').__version__)
     arrays['meta'] = np.array(json.dumps(meta))
     path = os.path.join(OUT, f'{tag}.npz')
     np.savez_compressed(path, **arrays)
-    print(f'[gen_golden] {tag}: bf16 envelope logits {float(env["emul/logits_rel_l2"]):.2e}, grads median '
-          f'{float(np.median([v for k, v in env.items() if k.startswith("emul/g/")])):.2e}')
+    if env:
+        print(f'[gen_golden] {tag}: bf16 envelope logits {float(env["emul/logits_rel_l2"]):.2e}, grads median '
+              f'{float(np.nanmedian(env["emul/g"])):.2e}')
     print(f'[gen_golden] {tag}: loss={float(out.loss):.6f} min-margin={float(arrays["margin"].min()):.4f} '
           f'params={sum(p.numel() for p in model.parameters())} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
 
@@ -268,6 +352,12 @@ def main():
         run_model_case('full_cfg1_concat', FULL, 'concat', 0, 21, False)
         run_model_case('full_cfg2_xattn', FULL, 'cross_attention', 0, 22, False)
         run_model_case('full_cfg3_mcan_moe4', FULL, 'mcan', 4, 23, False)
+    if args.only in ('all', 'full32'):
+        # BASELINE.json's batch (32 per GPU): 32 samples selected from a pool of 192 by reference margin (select_samples)
+        F32 = dict(FULL, batch=32)
+        run_model_case('full32_cfg1_concat', F32, 'concat', 0, 31, False, pool=192, emulate=False)
+        run_model_case('full32_cfg2_xattn', F32, 'cross_attention', 0, 32, False, pool=192, emulate=False)
+        run_model_case('full32_cfg3_mcan_moe4', F32, 'mcan', 4, 33, False, pool=192, emulate=False)
 
 
 if __name__ == '__main__':

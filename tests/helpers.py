@@ -19,6 +19,20 @@ def model_config_from_dims(d, fusion_type, num_experts, pooling='cls'):
         answer_head=AnswerHeadConfig(num_answers=d['num_answers'], hidden_dims=list(d['answer_hidden']), dropout=0.3))
 
 
+def fixture_inputs(arrays, meta):
+    """The seeded inputs of a golden fixture: ``det_weights.make_inputs``, or -- batch-32 fixtures -- the rows
+    ``arrays['pool_index']`` of ``det_weights.make_input_pool`` (the samples ``oracle/gen_golden.py: select_samples`` kept)."""
+    import torch
+    from oracle import det_weights as dw
+    d = meta['dims']
+    if meta.get('pool'):
+        px, ids, mask, labels = dw.make_input_pool(meta['pool'], d['seq'], d['image'], vocab_hi=min(30000, d['vocab']),
+                                                   num_answers=d['num_answers'], seed=meta['seed'])
+        idx = torch.from_numpy(arrays['pool_index'])
+        return px[idx], ids[idx], mask[idx], labels[idx]
+    return dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=min(30000, d['vocab']), num_answers=d['num_answers'], seed=meta['seed'])
+
+
 def build_model(meta):
     return VietnameseVQAModel(model_config_from_dims(meta['dims'], meta['fusion_type'], meta['num_experts']))
 

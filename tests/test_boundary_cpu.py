@@ -16,8 +16,12 @@ def test_library_exports_every_declared_symbol():
     from vqa_model_builder_amd.hip import lib
     declared = set(re.findall(r'\b(vqa_[a-z0-9_]+)\s*\(', open(os.path.join(REPO, 'include', 'vqa_hip.h')).read()))
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    l = lib.load()                      # types every entry point; AttributeError if one is missing
-    assert l.vqa_abi_version() == 1
+    try:
+        for kind, code in (('bf16', 0), ('fp16', 1)):      # both operand-type builds of the same sources export the same ABI
+            l = lib.set_half(kind)          # types every entry point; AttributeError if one is missing
+            assert l.vqa_abi_version() == 2 and l.vqa_half_kind() == code
+    finally:
+        lib.set_half('bf16')
 
 
 @pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_xattn_moe8', 'full_cfg2_xattn', 'full_cfg3_mcan_moe4'])

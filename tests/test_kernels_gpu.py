@@ -269,14 +269,66 @@ def test_cross_entropy_argmax():
     logits = rnd((B, Cn), 1, 2.0).to(DEV)
     logits[3, 100] = logits[3, 2000] = 50.0          # tie: first index wins like torch.argmax
     labels = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(1)).to(DEV)
-    loss, pred, lse = K.ce_argmax_fwd(logits, labels, B, Cn)
+    loss, pred, lse, nvalid = K.ce_argmax_fwd(logits, labels, B, Cn)
     lg = logits.clone().requires_grad_(True)
     ref = torch.nn.functional.cross_entropy(lg, labels)
-    assert torch.allclose(loss, ref, atol=1e-5)
+    assert torch.allclose(loss, ref, atol=1e-5) and float(nvalid) == B
     assert torch.equal(pred, logits.argmax(-1)) and pred[3].item() == 100
     (ref * 2.5).backward()
-    dl, dlb = K.ce_bwd(logits, labels, lse, torch.tensor(2.5, device=DEV), B, Cn, want_bf16=True)
+    dl, dlb = K.ce_bwd(logits, labels, lse, torch.tensor(2.5, device=DEV), B, Cn, nvalid=nvalid, want_bf16=True)
     assert torch.allclose(dl, lg.grad, atol=1e-7, rtol=1e-4)
+    K.check_device_status(DEV)                                   # nothing out of range so far
+
+
+def test_cross_entropy_ignore_index_and_out_of_range_labels():
+    """F.cross_entropy defaults (reference vqa_model.py:713): label -100 rows are skipped and not counted by the mean; a label
+    >= C is never dereferenced -- NaN loss + cleared status word instead of an out-of-bounds read; int32 labels are widened;
+    CPU / float labels raise on the host."""
+    from vqa_model_builder_amd.hip import ops
+    B, Cn = 9, 50
+    logits = rnd((B, Cn), 3, 2.0).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(2))
+    labels[2] = labels[7] = -100
+    loss, _ = ops.cross_entropy_argmax(logits, labels.to(DEV).int())      # int32 from a collator
+    lg = logits.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lg, labels.to(DEV))
+    assert torch.allclose(loss, ref, atol=1e-5)
+    (loss * 3.0).backward()
+    (ref * 3.0).backward()
+    assert torch.allclose(logits.grad, lg.grad, atol=1e-7, rtol=1e-4)
+    assert float(logits.grad[2].abs().max()) == 0.0 and float(logits.grad[7].abs().max()) == 0.0
+    K.check_device_status(DEV)
+    bad = labels.clone()
+    bad[4] = Cn + 3
+    loss_bad, _ = ops.cross_entropy_argmax(logits.detach(), bad.to(DEV))
+    assert math.isnan(float(loss_bad))
+    with pytest.raises(IndexError):
+        K.check_device_status(DEV)
+    K.check_device_status(DEV)                                   # the word was reset
+    with pytest.raises(RuntimeError):
+        ops.cross_entropy_argmax(logits.detach(), labels)        # CPU labels
+    with pytest.raises(RuntimeError):
+        ops.cross_entropy_argmax(logits.detach(), labels.to(DEV).float())
+
+
+def test_roberta_embeddings_reject_out_of_range_ids():
+    B, S, D, V, Pm = 2, 8, 32, 50, 12
+    ids = torch.randint(2, V, (B, S), generator=torch.Generator().manual_seed(0)).to(DEV)
+    word, pos, typ = rnd((V, D), 1).to(DEV), rnd((Pm, D), 2).to(DEV), rnd((1, D), 3).to(DEV)
+    K.roberta_embed_fwd(ids, word, pos, typ, B, S, D)
+    K.check_device_status(DEV)
+    ids[1, 2] = V + 5                                            # beyond the table: reads the padding row, flags
+    u, _ = K.roberta_embed_fwd(ids, word, pos, typ, B, S, D)
+    assert torch.isfinite(u).all()
+    with pytest.raises(IndexError):
+        K.check_device_status(DEV)
+    from vqa_model_builder_amd.modeling.meta_arch.backbones import RobertaBackbone
+    net = RobertaBackbone(vocab_size=V, hidden_size=32, num_hidden_layers=1, num_attention_heads=4, intermediate_size=64,
+                          max_position_embeddings=Pm).to(DEV)
+    with pytest.raises(ValueError):                              # 11 tokens need position ids up to 12 > 11
+        net(torch.zeros((1, 11), dtype=torch.long, device=DEV))
+    out = net(torch.full((1, 8), 3, dtype=torch.int32, device=DEV)).last_hidden_state     # int32 ids are widened
+    assert out.shape == (1, 8, 32) and torch.isfinite(out).all()
 
 
 def test_router_and_dispatch():
@@ -496,6 +548,73 @@ def test_fused_adamw_device_side_step_count_and_gradient_prescale():
         assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
         assert torch.allclose(a, c, atol=2e-6, rtol=2e-5)
     assert abs(float(o_pre.grad_norm()) - float(o_ref.grad_norm())) < 1e-4 * float(o_ref.grad_norm())
+
+
+def test_fused_adamw_loss_scale_skips_non_finite_steps_like_gradscaler():
+    """fp16 mode: FusedAdamW(loss_scale='dynamic') against torch.amp.GradScaler + clip_grad_norm_ + torch AdamW on the same scaled
+    gradients: un-scaling, the inf check (step skipped, scale halved), scale growth after `growth_interval` clean steps, and the
+    bias corrections that must not count skipped steps."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+    shapes = [(40, 24), (130,)]
+    base = [torch.randn(s, device=DEV) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone()) for t in base]
+    ref = [torch.nn.Parameter(t.clone()) for t in base]
+    opt = FusedAdamW(mine, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, loss_scale='dynamic', growth_interval=3)
+    o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.01)
+    scaler = torch.amp.GradScaler('cuda', init_scale=65536.0, growth_interval=3)
+    for step in range(9):
+        gs = [torch.randn(s, device=DEV) * (3.0 if step % 2 else 0.1) for s in shapes]
+        if step in (2, 6):
+            gs[0][3, 5] = float('inf')
+        s_mine, s_ref = opt.loss_scale, scaler.get_scale()
+        assert s_mine == s_ref, (step, s_mine, s_ref)
+        for p, q, g in zip(mine, ref, gs):
+            p.grad = g * s_mine
+            q.grad = g.clone() * s_ref
+        opt.step()
+        scaler.unscale_(o_ref)
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        scaler.step(o_ref)
+        scaler.update()
+        assert opt.found_inf() == (step in (2, 6))
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+    opt.sync_step_counts()
+    assert {int(st['step']) for st in opt.state.values()} == {7}            # 9 steps, 2 skipped
+    assert opt.loss_scale == scaler.get_scale()
+
+
+def test_fp16_library_gemm_layouts_exact_and_library_switch():
+    """The fp16 build (libvqa_hip_f16.so, v_mfma_f32_16x16x32_f16): same layouts, exact on integer data; the operand type is a
+    process-wide switch and both handles stay usable."""
+    try:
+        hl.set_half('fp16')
+        assert K.HALF() == torch.float16 and hl.load().vqa_half_kind() == 1
+        for (M, N, Kd) in [(256, 384, 192), (1600, 768, 768), (32, 768, 3000), (200, 2304, 776)]:
+            a, b = ints((M, Kd), seed=M + Kd).to(DEV), ints((N, Kd), seed=N + 7).to(DEV)
+            ref = a @ b.t()
+            out = torch.empty((M, N), dtype=F32, device=DEV)
+            K.gemm(a.half(), b.half(), M, N, Kd, Kd, Kd, True, True, out_f32=out)
+            assert torch.equal(out, ref), ('NT', M, N, Kd)
+            K.gemm(a.half(), b.t().contiguous().half(), M, N, Kd, Kd, N, True, False, out_f32=out)
+            assert torch.equal(out, ref), ('NN', M, N, Kd)
+            K.gemm(a.t().contiguous().half(), b.t().contiguous().half(), M, N, Kd, M, N, False, False, out_f32=out)
+            assert torch.equal(out, ref), ('TN', M, N, Kd)
+        x = rnd((64, 96), 5).to(DEV)
+        xh = K.cast_bf16(x)                                      # "the library's 16-bit type"
+        assert xh.dtype == torch.float16 and torch.equal(xh, x.half())
+        # attention at fp16 resolution (2^-11 relative), an order tighter than the bf16 library reaches
+        B, H, S, Dh = 2, 4, 50, 64
+        q, k, v = [rnd((B * S, H * Dh), 10 + i).to(DEV) for i in range(3)]
+        o = K.attention_fwd(q.half(), k.half(), v.half(), H * Dh, H * Dh, H * Dh, B, H, S, S, Dh)
+        qh, kh, vh = [t.half().float().view(B, S, H, Dh).transpose(1, 2) for t in (q, k, v)]
+        ref = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(Dh), -1) @ vh
+        err = (o.float().view(B, S, H, Dh).transpose(1, 2) - ref).abs().max().item()
+        assert err < 4e-3, err
+    finally:
+        hl.set_half('bf16')
+    assert K.HALF() == torch.bfloat16 and hl.load().vqa_half_kind() == 0
 
 
 def test_bilinear_as_one_gemm_over_outer_products():

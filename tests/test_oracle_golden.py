@@ -9,6 +9,7 @@ from oracle import det_weights as dw
 from oracle import vqa_oracle as vo
 from oracle.gen_golden import sample_grad
 from tests.conftest import CfgView, load_golden
+from tests.helpers import fixture_inputs
 
 TOL = 1e-5
 
@@ -25,8 +26,7 @@ def _run_case(tag):
     sd = dw.make_state_dict(shapes, meta['seed'])
     assert abs(dw.checksum(sd) - meta['weights_checksum']) <= 1e-6 * abs(meta['weights_checksum']), \
         'deterministic weight generator drifted from the one that made the fixture'
-    px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=min(30000, d['vocab']),
-                                           num_answers=d['num_answers'], seed=meta['seed'])
+    px, ids, mask, labels = fixture_inputs(arrays, meta)
     cfg = CfgView(meta)
     logits, loss, pred, grads = vo.forward_backward(sd, cfg, px, ids, mask, labels,
                                                     vit_heads=d['vit_heads'], text_heads=d['txt_heads'])
@@ -35,6 +35,7 @@ def _run_case(tag):
 
 TINY = ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_xattn_moe8', 'tiny_bilinear']
 FULL = ['full_cfg1_concat', 'full_cfg2_xattn', 'full_cfg3_mcan_moe4']
+FULL32 = ['full32_cfg1_concat', 'full32_cfg2_xattn', 'full32_cfg3_mcan_moe4']      # BASELINE batch: 32 selected pool samples
 
 
 def _check(tag, rich):
@@ -70,6 +71,26 @@ def test_oracle_matches_reference_tiny(tag):
 @pytest.mark.parametrize('tag', FULL)
 def test_oracle_matches_reference_full(tag):
     _check(tag, False)
+
+
+@pytest.mark.parametrize('tag', FULL32)
+def test_oracle_matches_reference_full_batch32(tag):
+    _check(tag, False)
+
+
+def test_fixtures_carry_the_reference_autocast_envelopes():
+    """Every model fixture stores what the reference itself does under torch.autocast (bf16 and fp16): the GPU parity gates
+    are multiples of THESE numbers.  Sanity: fp16 is the tighter one, and both are finite and in a plausible band."""
+    for tag in TINY + FULL + FULL32:
+        arrays, meta = load_golden(tag)
+        for mode in ('ac_bf16', 'ac_fp16'):
+            assert arrays[mode + '/g'].shape == (len(meta['grad_names']),) and arrays[mode + '/gs'].shape == (len(meta['grad_names']),)
+            assert arrays[mode + '/predictions'].shape == arrays['predictions'].shape
+        b, h = float(arrays['ac_bf16/logits_rel_l2']), float(arrays['ac_fp16/logits_rel_l2'])
+        assert 1e-3 < b < 3e-2 and 1e-4 < h < 4e-3 and h < b, (tag, b, h)
+        if meta.get('pool'):
+            assert arrays['pool_index'].shape == (meta['dims']['batch'],)
+            assert float(arrays['margin'].min()) > 4.0 * float(arrays['ac_bf16/logits_max_abs']), tag    # every answer id gateable exactly
 
 
 def test_parts_routers_combine_pooling():

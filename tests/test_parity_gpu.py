@@ -2,24 +2,27 @@
 (tests/golden/*.npz, oracle/gen_golden.py) and against the CPU oracle run live on the same seeded inputs.
 
 Mode: ``model.eval()`` with autograd enabled (dropout and router noise off), the only mode in which the reference's
-outputs are deterministic.
+outputs are deterministic.  Both operand types of the library are tested: 'bf16' (default) and 'fp16' (what the
+reference's main loop runs under: autocast fp16 + GradScaler; here a fixed loss scale of 1024, un-scaled before comparing).
 
-Tolerance.  The HIP path computes with bf16 GEMM operands and fp32 accumulation / LayerNorm / softmax / loss (the
-numeric scheme of torch autocast, which the reference's loops run under).  BASELINE.json's "1e-3 rel" is not reachable
-by ANY bf16 implementation of a 26-layer network: rounding every GEMM operand to bf16 inside the reference-pinned fp32
-oracle itself (``oracle/gen_golden.py: bf16_envelope``) moves the logits by 5e-3..1e-2 relative L2 and the parameter
-gradients by 1e-2..1.5e-1 on these fixtures.  Each fixture therefore carries that measured bf16 envelope per tensor
-(``emul/*``), and the HIP path is held to it:
-  * logits:              rel-L2 error vs the fp32 golden <= ENV x envelope + 1e-3
-  * parameter gradients: norm-weighted aggregate rel-L2 error of the fixture's samples <= max(ENV x aggregate envelope,
-                         0.25) and every tensor's gradient norm within 15 %; tensors at the fp32 noise floor must be
-                         small.  (Whole-model gradients at these inits are chaotic w.r.t. 2^-9 perturbations: two bf16
-                         realisations differ from each other as much as from fp32.  The tight, teacher-forced gradient
-                         checks -- <= 4e-2 per tensor, measured <= 1.2e-2 -- are in tests/test_blocks_gpu.py.)
-  * argmax answer ids:   bit-exact wherever the reference's top-1/top-2 margin exceeds 4x the measured max logit
-                         error; below that the pair is a numerical tie and the id must be one of the reference top-2.
-Per-kernel numerics (tests/test_kernels_gpu.py) are checked separately against fp32 torch at bf16 resolution (and
-EXACTLY for the GEMM layouts), so a layout or indexing bug cannot hide inside the envelope.
+Tolerances come FROM THE REFERENCE, not from us.  Each fixture stores what the reference itself does when it is run under
+``torch.autocast('cpu', bfloat16 | float16)`` -- the context its own training loops run the model in
+(training_pipeline.py:457, vqa_trainer.py:760-764) -- relative to its fp32 result on the same weights and inputs
+(``ac_bf16/*``, ``ac_fp16/*``: logits rel-L2 and max-abs, answer ids, per-parameter gradient error).  Measured there
+(full size): bf16 logits 0.9-1.05e-2, gradients 8-10e-2 aggregate; fp16 logits 1.0-1.3e-3, gradients 1.3-3.5e-2.  BASELINE.json's
+"1e-3 rel" is therefore the fp16 figure of the reference itself, and not reachable by any bf16 run of this 26-layer network
+-- the reference's own bf16 autocast included.  The HIP path is gated at
+
+  * logits            rel-L2 vs the fp32 golden <= ENV (1.5) x the reference's own autocast deviation in the same operand type;
+                      in fp16 mode additionally <= FP16_LOGITS_ABS (the north star's 1e-3 plus the measured fp16 rounding floor);
+  * answer ids        bit-exact on EVERY sample whose reference top-1/top-2 margin exceeds 4 x the measured max logit error --
+                      which is every sample of the batch-32 fixtures (margins >= 0.63 selected from a pool, oracle/gen_golden.py
+                      select_samples): the test asserts that no sample of those falls inside the tie band;
+  * gradients         norm-weighted aggregate rel-L2 error of the fixture's samples <= ENV x the same aggregate of the reference's
+                      autocast run (no absolute floor); every tensor's norm within max(15 %, ENV x the reference's own change);
+                      the five worst tensors are printed next to the reference's figure for them.
+Per-kernel numerics (tests/test_kernels_gpu.py) are checked separately against fp32 torch (and EXACTLY for the GEMM layouts);
+teacher-forced per-block gradients (<= 4e-2 per tensor) in tests/test_blocks_gpu.py.
 """
 
 import numpy as np
@@ -32,13 +35,12 @@ from oracle import det_weights as dw  # noqa: E402
 from oracle import vqa_oracle as vo  # noqa: E402
 from oracle.gen_golden import sample_grad  # noqa: E402
 from tests.conftest import CfgView, load_golden  # noqa: E402
-from tests.helpers import build_model  # noqa: E402
+from tests.helpers import build_model, fixture_inputs  # noqa: E402
 
-ENV = 2.5            # allowed multiple of the measured bf16 envelope
-NORM_TOL = 0.15      # every gradient tensor's norm
-GLOBAL_FLOOR = 0.25  # norm-weighted aggregate gradient error: the whole-model backward is chaotic at these inits (a ReLU
-                     # or routing-adjacent flip upstream re-draws the noise), so the aggregate is a sanity bound against
-                     # structural errors; the tight per-block gradient checks live in tests/test_blocks_gpu.py
+ENV = 1.5                # allowed multiple of the reference's own autocast deviation
+NORM_TOL = 0.15          # every gradient tensor's norm
+FP16_LOGITS_ABS = 2e-3   # fp16 mode, logits rel-L2 vs fp32: north star 1e-3 + the fp16 floor the reference itself shows (1.0-1.3e-3)
+MODES = {'bf16': ('ac_bf16', 1.0), 'fp16': ('ac_fp16', 1024.0)}
 DEV = 'cuda'
 
 
@@ -47,27 +49,37 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def run_case(tag, rich, with_oracle=False):
+def run_case(tag, rich, mode='bf16', with_oracle=False):
+    import vqa_model_builder_amd as vqa
+    vqa.set_compute_dtype(mode)
+    try:
+        return _run_case(tag, rich, mode, with_oracle)
+    finally:
+        vqa.set_compute_dtype('bf16')
+
+
+def _run_case(tag, rich, mode, with_oracle):
     arrays, meta = load_golden(tag)
+    ac, scale = MODES[mode]
     d = meta['dims']
     shapes = {k: tuple(v) for k, v in meta['shapes'].items()}
     sd = dw.make_state_dict(shapes, meta['seed'])
-    px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=min(30000, d['vocab']),
-                                           num_answers=d['num_answers'], seed=meta['seed'])
+    px, ids, mask, labels = fixture_inputs(arrays, meta)
     model = build_model(meta)
     model.load_state_dict(sd)
     model = model.to(DEV).eval()
     with torch.enable_grad():
         out = model(pixel_values=px.to(DEV), input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV),
                     return_features=True)
-        out.loss.backward()
+        (out.loss * scale).backward()                # fp16: the loss scale GradScaler would apply (un-scaled below)
     torch.cuda.synchronize()
     logits = out.logits.detach().float().cpu().numpy()
-    report = {'tag': tag}
+    report = {'tag': tag, 'mode': mode}
     # ---- routing: top-k expert choice is discrete.  A sample whose k-th and (k+1)-th router probabilities are a numerical tie in
-    # the reference (closer than 4x the measured probability error) may legitimately take the other expert under bf16 operands:
-    # such samples are excluded from the logit comparison and the gradient comparison is skipped (one different expert changes
-    # every gradient); a flip OUTSIDE a tie is an error.  (tiny_xattn_moe8, sample 0: 0.1175 vs 0.1180.)
+    # the reference (closer than 4x the measured probability error) may legitimately take the other expert at 16-bit operands -- the
+    # reference under its own fp16 autocast flips the same sample of tiny_xattn_moe8 (0.1175 vs 0.1180): such samples are excluded
+    # from the logit comparison and the gradient comparison is skipped; a flip OUTSIDE a tie is an error.  The batch-32 fixtures
+    # contain no such sample by construction (router gap > 0.02).
     keep = np.ones(logits.shape[0], dtype=bool)
     if meta['num_experts'] > 0:
         got_p = model.moe_layer.aux_outputs['router_probs'].detach().float().cpu().numpy().reshape(logits.shape[0], -1)
@@ -81,13 +93,17 @@ def run_case(tag, rich, with_oracle=False):
                 keep[b] = False
         report['routing_tie_flips'] = int((~keep).sum())
         assert keep.sum() >= max(1, logits.shape[0] // 2), report
+        if meta.get('pool'):
+            assert keep.all(), report
     # ---- forward
     report['logits_rel_l2'] = rel_l2(logits[keep], arrays['logits'][keep])
     report['logits_max_abs'] = float(np.abs(logits[keep] - arrays['logits'][keep]).max())
     report['loss_abs'] = abs(float(out.loss) - float(arrays['loss']))
     report['fused_rel_l2'] = rel_l2(out.fused_features.detach().float().cpu().numpy()[keep], arrays['fused'][keep])
-    logit_tol = ENV * float(arrays['emul/logits_rel_l2']) + 1e-3
-    report['logits_envelope'] = float(arrays['emul/logits_rel_l2'])
+    report['ref_autocast_logits'] = float(arrays[ac + '/logits_rel_l2'])
+    logit_tol = ENV * report['ref_autocast_logits']
+    if mode == 'fp16':
+        logit_tol = min(logit_tol, FP16_LOGITS_ABS)
     assert report['logits_rel_l2'] <= logit_tol, report
     if keep.all():
         assert report['loss_abs'] <= logit_tol * max(1.0, abs(float(arrays['loss']))), report
@@ -106,7 +122,11 @@ def run_case(tag, rich, with_oracle=False):
             n_tie += 1
             assert pred[b] in top2[b], (tag, b, pred[b], top2[b])
     report['argmax_exact'] = int((pred == ref_pred).sum())
+    report['argmax_gated_exact'] = int(keep.sum()) - n_tie
     report['argmax_ties'] = n_tie
+    report['min_margin_over_max_err'] = float(margin[keep].min() / max(report['logits_max_abs'], 1e-12))
+    if meta.get('pool'):
+        assert n_tie == 0 and report['argmax_exact'] == len(pred), report          # every sample gated bit-exact
     # ---- gradients
     named = dict(model.named_parameters())
     if not keep.all():      # a tie-flipped expert choice changes every gradient: only sanity here (block-level tests cover them)
@@ -115,35 +135,33 @@ def run_case(tag, rich, with_oracle=False):
         for name in meta['none_grad_names']:
             g = named[name].grad
             assert g is None or float(g.abs().max()) == 0.0, f'{name} must not receive a gradient'
-        worst_g, worst_n, worst_name = 0.0, 0.0, ''
-        ratios, num, den, env_num = [], 0.0, 0.0, 0.0
+        ref_full = dict(zip(meta['grad_names'], arrays[ac + '/g'].tolist()))
+        ref_samp = dict(zip(meta['grad_names'], arrays[ac + '/gs'].tolist()))
+        rows, num, den, env_num, worst_n = [], 0.0, 0.0, 0.0, 0.0
         gmax = max(float(arrays['gnorm/' + n]) for n in meta['grad_names'])
         for name in meta['grad_names']:
             g = named[name].grad
             assert g is not None, f'missing gradient for {name}'
-            g = g.detach().float().cpu()
+            g = g.detach().float().cpu() / scale
             ref_n = float(arrays['gnorm/' + name])
             if ref_n < 1e-4 * gmax:          # exactly-zero / noise-floor gradients (e.g. k_proj.bias): only require smallness
                 assert float(g.norm()) <= 1e-2 * gmax, (name, float(g.norm()), ref_n)
                 continue
             en = abs(float(g.double().norm()) - ref_n) / ref_n
             es = rel_l2(sample_grad(g, rich).numpy(), arrays['g/' + name])
-            env = float(arrays['emul/g/' + name])
-            if es > worst_g:
-                worst_g, worst_name = es, name
+            rows.append((es, ref_samp[name], name))
             worst_n = max(worst_n, en)
-            ratios.append(es / max(env, 1e-3))
             num += (es * ref_n) ** 2
-            env_num += (env * ref_n) ** 2
+            env_num += (ref_samp[name] * ref_n) ** 2
             den += ref_n ** 2
-            # norm of each gradient: fixed tolerance, widened for the parameters whose gradient the bf16 emulation itself moves by
-            # more (the router gate of the full-size MoE config: emulation envelope 0.12 on a norm of 1.45)
-            assert en <= max(NORM_TOL, ENV * env), (tag, name, 'gradient norm', en, env)
+            assert en <= max(NORM_TOL, ENV * ref_full[name]), (tag, name, 'gradient norm', en, ref_full[name])
         report['grad_global_rel_l2'] = float(np.sqrt(num / den))
-        report['grad_global_envelope'] = float(np.sqrt(env_num / den))
-        report['grad_worst_rel_l2'], report['grad_worst_name'], report['gnorm_worst_rel'] = worst_g, worst_name, worst_n
-        report['grad_err_over_envelope_median'] = float(np.median(ratios))
-        assert report['grad_global_rel_l2'] <= max(ENV * report['grad_global_envelope'], GLOBAL_FLOOR), report
+        report['ref_autocast_grad_global'] = float(np.sqrt(env_num / den))
+        report['gnorm_worst_rel'] = worst_n
+        rows.sort(reverse=True)
+        report['grad_err_over_ref_median'] = float(np.median([r[0] / max(r[1], 1e-4) for r in rows]))
+        report['worst5'] = '; '.join(f'{n}: {e:.3f} (ref {r:.3f})' for e, r, n in rows[:5])
+        assert report['grad_global_rel_l2'] <= ENV * report['ref_autocast_grad_global'], report
     if meta['num_experts'] > 0:
         aux = model.moe_layer.aux_outputs
         report['router_probs_max_abs'] = float(np.abs(aux['router_probs'].detach().cpu().numpy() - arrays['router_probs']).max())
@@ -158,19 +176,32 @@ def run_case(tag, rich, with_oracle=False):
     return report
 
 
-@pytest.mark.parametrize('tag', ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_bilinear', 'tiny_xattn_moe8'])
-def test_tiny_against_reference_golden_and_oracle(tag):
-    run_case(tag, True, with_oracle=True)
+TINY_TAGS = ['tiny_concat', 'tiny_xattn', 'tiny_mcan_moe4', 'tiny_bilinear', 'tiny_xattn_moe8']
 
 
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('tag', TINY_TAGS)
+def test_tiny_against_reference_golden_and_oracle(tag, mode):
+    run_case(tag, True, mode, with_oracle=True)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
 @pytest.mark.parametrize('tag', ['full_cfg1_concat', 'full_cfg2_xattn', 'full_cfg3_mcan_moe4'])
-def test_full_size_against_reference_golden(tag):
-    run_case(tag, False)
+def test_full_size_against_reference_golden(tag, mode):
+    run_case(tag, False, mode)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('tag', ['full32_cfg1_concat', 'full32_cfg2_xattn', 'full32_cfg3_mcan_moe4'])
+def test_full_size_batch32_every_answer_id_exact(tag, mode):
+    """BASELINE.json's batch (32 per GPU) at full size: logits / gradients against the reference's goldens and the answer id of
+    EVERY sample gated bit-exact (reference margins >= 0.63, an order of magnitude above the measured 16-bit logit error)."""
+    run_case(tag, False, mode)
 
 
 def test_full_size_properties_batch32():
-    """BASELINE.json's full size (B = 32/GPU) through size-independent properties: per-sample independence of the
-    data-parallel path (a sample's logits do not depend on its batch-mates) and determinism of eval forward."""
+    """Size-independent properties at B = 32: per-sample independence of the data-parallel path (a sample's logits do not
+    depend on its batch-mates) and determinism of the eval forward."""
     _, meta = load_golden('full_cfg2_xattn')
     d = meta['dims']
     sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])

@@ -9,7 +9,22 @@ import importlib
 import sys
 import types
 
-__version__ = '0.1.0'
+__version__ = '0.2.0'
+
+
+def set_compute_dtype(kind: str = 'bf16'):
+    """'bf16' (default) or 'fp16': the 16-bit type of every GEMM / attention operand (fp32 accumulation, fp32 LayerNorm / softmax /
+    loss / residual stream and fp32 master weights and gradients either way).  'fp16' is the dtype of the reference's main loop
+    (autocast fp16 + GradScaler, training_pipeline.py:346-347,457): the caller scales the loss (``GradScaler`` or
+    ``optim.FusedAdamW(loss_scale=...)``) exactly as it does for the reference.  Process-wide; call before the model is built."""
+    from .hip import lib
+    lib.set_half(kind)
+    return kind
+
+
+def compute_dtype() -> str:
+    from .hip import lib
+    return lib.half()
 
 _ALIASES = {
     'src.modeling.meta_arch': 'vqa_model_builder_amd.modeling.meta_arch',

@@ -14,8 +14,8 @@ namespace {
 constexpr int NT = 256, NW = 4;
 
 struct AttnArgs {
-    const bf16_t *q, *k, *v, *d_o;
-    bf16_t *o, *dq, *dk, *dv;
+    const h16_t *q, *k, *v, *d_o;
+    h16_t *o, *dq, *dk, *dv;
     int ldq, ldk, ldv, ldo, ldd_o, lddq, lddk, lddv;
     int B, H, Sq, Skv, Dh;
     const uint8_t* mask;
@@ -33,7 +33,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void load_tile(bf16_t* lds, const bf16_t* g, int rows, int Dh, int ld, int pitch, int tid) {
+__device__ __forceinline__ void load_tile(h16_t* lds, const h16_t* g, int rows, int Dh, int ld, int pitch, int tid) {
     const int half = Dh / 2;
     for (int t = tid; t < rows * half; t += NT) {
         const int r = t / half, c = t % half;
@@ -41,10 +41,10 @@ __device__ __forceinline__ void load_tile(bf16_t* lds, const bf16_t* g, int rows
     }
 }
 
-__device__ __forceinline__ float dot_row(const float* qrow, const bf16_t* krow, int Dh) {
+__device__ __forceinline__ float dot_row(const float* qrow, const h16_t* krow, int Dh) {
     float acc = 0.f;
     for (int d = 0; d < Dh; d += 2) {
-        const bf16x2 kk = *reinterpret_cast<const bf16x2*>(krow + d);
+        const h16x2 kk = *reinterpret_cast<const h16x2*>(krow + d);
         acc += qrow[d] * (float)kk[0] + qrow[d + 1] * (float)kk[1];
     }
     return acc;
@@ -52,7 +52,7 @@ __device__ __forceinline__ float dot_row(const float* qrow, const bf16_t* krow, 
 
 // scores -> probabilities for the wave's current query row; returns p (normalised, NOT dropped) for key slots
 // j0 = lane, j1 = lane + 64, and the dropout keep-scales.
-__device__ __forceinline__ void row_softmax(const AttnArgs& a, const float* qrow, const bf16_t* Ks, int pitch, int b, int h, int qi,
+__device__ __forceinline__ void row_softmax(const AttnArgs& a, const float* qrow, const h16_t* Ks, int pitch, int b, int h, int qi,
                                             int lane, float& p0, float& p1, float& ks0, float& ks1) {
     const int j0 = lane, j1 = lane + 64;
     float s0 = -INFINITY, s1 = -INFINITY;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs a_in) {
     if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pitch = a.Dh + 2;
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + a.Skv * pitch;
+    h16_t* Ks = reinterpret_cast<h16_t*>(smem);
+    h16_t* Vs = Ks + a.Skv * pitch;
     float* qbuf = reinterpret_cast<float*>(Vs + a.Skv * pitch);       // [NW][Dh]
     float* pbuf = qbuf + NW * a.Dh;                                    // [NW][128]
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs a_in) {
     float* qrow = qbuf + wave * a.Dh;
     float* prow = pbuf + wave * 128;
     for (int qi = blockIdx.y * NW + wave; qi < a.Sq; qi += gridDim.y * NW) {
-        const bf16_t* qg = a.q + ((size_t)b * a.Sq + qi) * a.ldq + h * a.Dh;
+        const h16_t* qg = a.q + ((size_t)b * a.Sq + qi) * a.ldq + h * a.Dh;
         wave_sync();
         for (int d = lane; d < a.Dh; d += 64) qrow[d] = (float)qg[d];
         wave_sync();
@@ -98,11 +98,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const AttnArgs a_in) {
         prow[lane] = p0 * ks0;
         prow[lane + 64] = p1 * ks1;
         wave_sync();
-        bf16_t* og = a.o + ((size_t)b * a.Sq + qi) * a.ldo + h * a.Dh;
+        h16_t* og = a.o + ((size_t)b * a.Sq + qi) * a.ldo + h * a.Dh;
         for (int d = lane; d < a.Dh; d += 64) {
             float acc = 0.f;
             for (int j = 0; j < a.Skv; ++j) acc += prow[j] * (float)Vs[j * pitch + d];
-            og[d] = (bf16_t)acc;
+            og[d] = (h16_t)acc;
         }
     }
 }
@@ -114,10 +114,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a_in) {
     const int pitch = a.Dh + 2, pp = a.Skv + 1;
     const bool phaseA = a.mode != 2, phaseB = a.mode != 1;
     // LDS: [K, V] (phase A) [Q, dO] (phase B or mode 0) [P', dS] (mode 0 only) [per-wave rows] (phase A)
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + (phaseA ? a.Skv * pitch : 0);
-    bf16_t* Qs = Vs + (phaseA ? a.Skv * pitch : 0);
-    bf16_t* Gs = Qs + (a.mode != 1 ? a.Sq * pitch : 0);               // dO
+    h16_t* Ks = reinterpret_cast<h16_t*>(smem);
+    h16_t* Vs = Ks + (phaseA ? a.Skv * pitch : 0);
+    h16_t* Qs = Vs + (phaseA ? a.Skv * pitch : 0);
+    h16_t* Gs = Qs + (a.mode != 1 ? a.Sq * pitch : 0);               // dO
     float* Ps = reinterpret_cast<float*>(Gs + (a.mode != 1 ? a.Sq * pitch : 0));     // [Sq][Skv+1] dropped probabilities
     float* Ds = Ps + (a.mode == 0 ? a.Sq * pp : 0);                    // [Sq][Skv+1] dS
     float* qbuf = Ds + (a.mode == 0 ? a.Sq * pp : 0);                  // [NW][Dh] fp32 q row
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a_in) {
     }
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bf16_t* qg0 = a.q + (size_t)b * a.Sq * a.ldq + h * a.Dh;
-    const bf16_t* gg0 = a.d_o + (size_t)b * a.Sq * a.ldd_o + h * a.Dh;
+    const h16_t* qg0 = a.q + (size_t)b * a.Sq * a.ldq + h * a.Dh;
+    const h16_t* gg0 = a.d_o + (size_t)b * a.Sq * a.ldd_o + h * a.Dh;
     if (phaseA) {
         load_tile(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * a.Dh, a.Skv, a.Dh, a.ldk, pitch, tid);
         load_tile(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * a.Dh, a.Skv, a.Dh, a.ldv, pitch, tid);
@@ -165,11 +165,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a_in) {
             if (j1 < a.Skv) { Ps[qi * pp + j1] = p1 * ks1; Ds[qi * pp + j1] = ds1; }
             srow[j0] = ds0; srow[j1] = ds1;
             wave_sync();
-            bf16_t* dqg = a.dq + ((size_t)b * a.Sq + qi) * a.lddq + h * a.Dh;
+            h16_t* dqg = a.dq + ((size_t)b * a.Sq + qi) * a.lddq + h * a.Dh;
             for (int d = lane; d < a.Dh; d += 64) {
                 float acc = 0.f;
                 for (int j = 0; j < a.Skv; ++j) acc += srow[j] * (float)Ks[j * pitch + d];
-                dqg[d] = (bf16_t)acc;
+                dqg[d] = (h16_t)acc;
             }
         }
         __syncthreads();
@@ -177,16 +177,16 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const AttnArgs a_in) {
     if (!phaseB) return;
     // phase B: per key row -> dK, dV
     for (int j = wave; j < a.Skv; j += NW) {
-        bf16_t* dkg = a.dk + ((size_t)b * a.Skv + j) * a.lddk + h * a.Dh;
-        bf16_t* dvg = a.dv + ((size_t)b * a.Skv + j) * a.lddv + h * a.Dh;
+        h16_t* dkg = a.dk + ((size_t)b * a.Skv + j) * a.lddk + h * a.Dh;
+        h16_t* dvg = a.dv + ((size_t)b * a.Skv + j) * a.lddv + h * a.Dh;
         for (int d = lane; d < a.Dh; d += 64) {
             float ak = 0.f, av = 0.f;
             for (int qi = 0; qi < a.Sq; ++qi) {
                 ak += Ds[qi * pp + j] * (float)Qs[qi * pitch + d];
                 av += Ps[qi * pp + j] * (float)Gs[qi * pitch + d];
             }
-            dkg[d] = (bf16_t)ak;
-            dvg[d] = (bf16_t)av;
+            dkg[d] = (h16_t)ak;
+            dvg[d] = (h16_t)av;
         }
     }
 }
@@ -196,15 +196,15 @@ int fill_args(const VqaAttnDesc* d, AttnArgs& a, bool bwd) {
     if (d->B <= 0 || d->H <= 0 || d->Sq <= 0 || d->Skv <= 0 || d->Sq > 128 || d->Skv > 128) return VQA_ERR_ARG;
     if (d->Dh <= 0 || d->Dh > 256 || d->Dh % 2) return VQA_ERR_ARG;
     if ((d->ldq | d->ldk | d->ldv) % 2) return VQA_ERR_ARG;
-    a.q = (const bf16_t*)d->q; a.k = (const bf16_t*)d->k; a.v = (const bf16_t*)d->v; a.o = (bf16_t*)d->o;
+    a.q = (const h16_t*)d->q; a.k = (const h16_t*)d->k; a.v = (const h16_t*)d->v; a.o = (h16_t*)d->o;
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv; a.Dh = d->Dh;
     a.mask = d->key_padding_mask;
     a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)d->Dh);
     a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     a.seed = d->drop_seed; a.stream = d->drop_stream;
-    a.d_o = (const bf16_t*)d->d_o; a.ldd_o = d->ldd_o;
-    a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
+    a.d_o = (const h16_t*)d->d_o; a.ldd_o = d->ldd_o;
+    a.dq = (h16_t*)d->dq; a.dk = (h16_t*)d->dk; a.dv = (h16_t*)d->dv;
     a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
     a.mode = 0; a.ws = nullptr;
     if (!bwd && !d->o) return VQA_ERR_ARG;

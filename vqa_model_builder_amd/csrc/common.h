@@ -7,10 +7,23 @@
 #define VQA_OK 0
 #define VQA_ERR_ARG 1001      // bad dims / alignment / unsupported combination
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// The 16-bit operand type of THIS build of the library.  The sources are compiled twice: libvqa_hip.so with bfloat16
+// operands (torch autocast's bf16 scheme) and libvqa_hip_f16.so (-DVQA_HALF_F16) with IEEE fp16 operands -- the dtype the
+// reference's main loop runs under (autocast fp16 + GradScaler, training_pipeline.py:346-347,457).  Everything else is
+// identical: fp32 accumulation, fp32 LayerNorm / softmax / loss / residual stream, same tiles, same MFMA shape.  Entry points
+// keep their names ("..._bf16" = "the library's 16-bit type"); vqa_half_kind() tells which build a handle is.
+#ifdef VQA_HALF_F16
+typedef _Float16 h16_t;
+#define VQA_HALF_KIND 1
+#define VQA_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)      // v_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 h16_t;
+#define VQA_HALF_KIND 0
+#define VQA_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)     // v_mfma_f32_16x16x32_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) h16_t h16x8;
+typedef __attribute__((ext_vector_type(4))) h16_t h16x4;
+typedef __attribute__((ext_vector_type(2))) h16_t h16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -19,8 +32,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 enum VqaAct { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3 };
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
-__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
+__device__ __forceinline__ float bf2f(h16_t v) { return (float)v; }
+__device__ __forceinline__ h16_t f2bf(float v) { return (h16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-safe
 
 // Cross-lane reductions.  __shfl_xor compiles to ds_bpermute_b32 on gfx950 -- an LDS-crossbar round trip of ~100 cycles per
 // step, and a reduction is a chain of them (measured: the bias-gradient column sums cost the attention backward 5000 cycles

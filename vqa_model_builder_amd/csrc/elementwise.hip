@@ -11,21 +11,21 @@ inline int grid_for(size_t work_items) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, h16_t* __restrict__ dst, size_t n) {
     const size_t n8 = n / 8;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
         const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
         const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
-        bf16x8 o;
+        h16x8 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j] = (bf16_t)a[j]; o[4 + j] = (bf16_t)b[j]; }
-        reinterpret_cast<bf16x8*>(dst)[i] = o;
+        for (int j = 0; j < 4; ++j) { o[j] = (h16_t)a[j]; o[4 + j] = (h16_t)b[j]; }
+        reinterpret_cast<h16x8*>(dst)[i] = o;
     }
-    for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)src[i];
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (h16_t)src[i];
 }
 
-__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+__global__ void cast_bf16_f32_kernel(const h16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
 }
@@ -38,17 +38,17 @@ __global__ void cast_multi_kernel(const VqaCastJob* __restrict__ jobs) {
     const float* src = job.src;
     const bool vec_ok = (((uintptr_t)src | (uintptr_t)job.dst) & 15) == 0;
     if (job.kind == 0) {
-        bf16_t* dst = (bf16_t*)job.dst;
+        h16_t* dst = (h16_t*)job.dst;
         size_t n8 = vec_ok ? n / 8 : 0;
         for (size_t i = t0; i < n8; i += stride) {
             const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
             const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
-            bf16x8 o;
+            h16x8 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { o[j] = (bf16_t)a[j]; o[4 + j] = (bf16_t)b[j]; }
-            reinterpret_cast<bf16x8*>(dst)[i] = o;
+            for (int j = 0; j < 4; ++j) { o[j] = (h16_t)a[j]; o[4 + j] = (h16_t)b[j]; }
+            reinterpret_cast<h16x8*>(dst)[i] = o;
         }
-        for (size_t i = n8 * 8 + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
+        for (size_t i = n8 * 8 + t0; i < n; i += stride) dst[i] = (h16_t)src[i];
     } else {
         float* dst = (float*)job.dst;
         size_t n4 = vec_ok ? n / 4 : 0;
@@ -87,29 +87,29 @@ int colsum_launch(const T* x, int M, int N, int ld, float* out, hipStream_t s) {
 }
 
 __global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                               bf16_t* __restrict__ yb, size_t n) {
+                               h16_t* __restrict__ yb, size_t n) {
     const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const f32x4 v = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
         if (y) reinterpret_cast<f32x4*>(y)[i] = v;
-        if (yb) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j]; reinterpret_cast<bf16x4*>(yb)[i] = o; }
+        if (yb) { h16x4 o; for (int j = 0; j < 4; ++j) o[j] = (h16_t)v[j]; reinterpret_cast<h16x4*>(yb)[i] = o; }
     }
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ dst,
-                                   bf16_t* __restrict__ dstb, int n, int D, int ld_src) {
+                                   h16_t* __restrict__ dstb, int n, int D, int ld_src) {
     const int d4 = D / 4;
     const size_t total = (size_t)n * d4, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int i = (int)(t / d4), c = (int)(t % d4);
         const f32x4 v = reinterpret_cast<const f32x4*>(src + (size_t)idx[i] * ld_src)[c];
         if (dst) reinterpret_cast<f32x4*>(dst + (size_t)i * D)[c] = v;
-        if (dstb) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j]; reinterpret_cast<bf16x4*>(dstb + (size_t)i * D)[c] = o; }
+        if (dstb) { h16x4 o; for (int j = 0; j < 4; ++j) o[j] = (h16_t)v[j]; reinterpret_cast<h16x4*>(dstb + (size_t)i * D)[c] = o; }
     }
 }
 
 // pixels [B,C,H,W] fp32 -> out [B*P, C*ps*ps] bf16, row (b, py, px), column (c, kh, kw).  One thread = 4 kw.
-__global__ void patchify_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int B, int C, int H, int W, int ps) {
+__global__ void patchify_kernel(const float* __restrict__ px, h16_t* __restrict__ out, int B, int C, int H, int W, int ps) {
     const int gw = W / ps, gh = H / ps, P = gw * gh, Kc = C * ps * ps, q4 = ps / 4;
     const size_t total = (size_t)B * P * C * ps * q4, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -120,8 +120,8 @@ __global__ void patchify_kernel(const float* __restrict__ px, bf16_t* __restrict
         const int p = (int)(r % P); const int b = (int)(r / P);
         const int py = p / gw, pxx = p % gw;
         const f32x4 v = *reinterpret_cast<const f32x4*>(px + (((size_t)b * C + c) * H + (py * ps + kh)) * W + pxx * ps + kw4 * 4);
-        bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-        *reinterpret_cast<bf16x4*>(out + ((size_t)b * P + p) * Kc + (c * ps + kh) * ps + kw4 * 4) = o;
+        h16x4 o; for (int j = 0; j < 4; ++j) o[j] = (h16_t)v[j];
+        *reinterpret_cast<h16x4*>(out + ((size_t)b * P + p) * Kc + (c * ps + kh) * ps + kw4 * 4) = o;
     }
 }
 
@@ -140,7 +140,7 @@ __global__ void clip_assemble_kernel(const float* __restrict__ E, const float* _
 }
 
 // dpos[tok,:] = sum_b du[b,tok,:]; dcls = dpos-like sum of tok 0; dE = bf16(du[b,1+p,:]).  grid = (T, ceil(D/256))
-__global__ void clip_assemble_bwd_kernel(const float* __restrict__ du, bf16_t* __restrict__ dE, float* __restrict__ dcls,
+__global__ void clip_assemble_bwd_kernel(const float* __restrict__ du, h16_t* __restrict__ dE, float* __restrict__ dcls,
                                          float* __restrict__ dpos, int B, int P, int D) {
     const int T = P + 1, tok = blockIdx.x, d = blockIdx.y * blockDim.x + threadIdx.x;
     if (d >= D) return;
@@ -148,15 +148,15 @@ __global__ void clip_assemble_bwd_kernel(const float* __restrict__ du, bf16_t* _
     for (int b = 0; b < B; ++b) {
         const float v = du[((size_t)b * T + tok) * D + d];
         acc += v;
-        if (tok > 0) dE[((size_t)b * P + tok - 1) * D + d] = (bf16_t)v;
+        if (tok > 0) dE[((size_t)b * P + tok - 1) * D + d] = (h16_t)v;
     }
     dpos[(size_t)tok * D + d] = acc;
     if (tok == 0) dcls[d] = acc;
 }
 
 // dpre = dy * act'(pre) * dropmask(idx)   (backward of y = drop(act(pre)) when it is not fused into a GEMM epilogue)
-__global__ void act_drop_bwd_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ pre, int act, float* __restrict__ out,
-                                    bf16_t* __restrict__ outb, size_t n, float p, float inv_keep, uint64_t seed, uint32_t stream) {
+__global__ void act_drop_bwd_kernel(const float* __restrict__ dy, const h16_t* __restrict__ pre, int act, float* __restrict__ out,
+                                    h16_t* __restrict__ outb, size_t n, float p, float inv_keep, uint64_t seed, uint32_t stream) {
     if (p > 0.f) seed = resolve_seed(seed);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -164,7 +164,7 @@ __global__ void act_drop_bwd_kernel(const float* __restrict__ dy, const bf16_t* 
         if (pre) v *= act_bwd((float)pre[i], act);
         if (p > 0.f) v *= dropout_scale(seed, stream, i, p, inv_keep);
         if (out) out[i] = v;
-        if (outb) outb[i] = (bf16_t)v;
+        if (outb) outb[i] = (h16_t)v;
     }
 }
 
@@ -188,7 +188,7 @@ __global__ void adamw_kernel(const VqaAdamWDesc d) {
     const float step_size = d.lr / d.bias_correction1;
     const float inv_sqrt_bc2 = rsqrtf(d.bias_correction2);
     const uint64_t n4 = d.n / 4, stride = (uint64_t)gridDim.x * blockDim.x;
-    bf16_t* shadow = (bf16_t*)d.param_bf16;
+    h16_t* shadow = (h16_t*)d.param_bf16;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         f32x4 p = reinterpret_cast<f32x4*>(d.param)[i];
         const f32x4 g = reinterpret_cast<const f32x4*>(d.grad)[i] * gs;
@@ -205,7 +205,7 @@ __global__ void adamw_kernel(const VqaAdamWDesc d) {
         reinterpret_cast<f32x4*>(d.param)[i] = p;
         reinterpret_cast<f32x4*>(d.exp_avg)[i] = m;
         reinterpret_cast<f32x4*>(d.exp_avg_sq)[i] = v;
-        if (shadow) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16_t)p[j]; reinterpret_cast<bf16x4*>(shadow)[i] = o; }
+        if (shadow) { h16x4 o; for (int j = 0; j < 4; ++j) o[j] = (h16_t)p[j]; reinterpret_cast<h16x4*>(shadow)[i] = o; }
     }
     for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
         float p = d.param[i] * (1.f - d.lr * d.weight_decay);
@@ -214,7 +214,7 @@ __global__ void adamw_kernel(const VqaAdamWDesc d) {
         const float v = d.beta2 * d.exp_avg_sq[i] + (1.f - d.beta2) * g * g;
         p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + d.eps));
         d.param[i] = p; d.exp_avg[i] = m; d.exp_avg_sq[i] = v;
-        if (shadow) shadow[i] = (bf16_t)p;
+        if (shadow) shadow[i] = (h16_t)p;
     }
 }
 
@@ -247,7 +247,14 @@ __global__ void sumsq_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
 // hyper (optional, device): {lr, step}: read at run time so a captured graph follows the schedule and the step count.
 __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uint32_t* __restrict__ chunks, const float* __restrict__ norm2,
                                    float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2,
-                                   const float* __restrict__ hyper, float prescale) {
+                                   const float* __restrict__ hyper, float prescale, const float* __restrict__ amp) {
+    if (amp) {
+        // fp16 mode: the gradients in memory are loss_scale x the true ones (amp[0], GradScaler's role); norm2 is the sum of
+        // squares of those scaled values: a non-finite one anywhere makes it non-finite and the whole step is skipped, exactly
+        // as GradScaler.step() skips optimizer.step() (reference training_pipeline.py:495-502)
+        if (!isfinite(norm2[0])) return;
+        prescale /= amp[0];
+    }
     if (hyper) {
         lr = hyper[0];
         const float t = hyper[1];
@@ -279,7 +286,7 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
         *reinterpret_cast<f32x4*>(j.exp_avg + i) = m;
         *reinterpret_cast<f32x4*>(j.exp_avg_sq + i) = v;
         if (j.shadow) {
-            if (j.shadow_kind == 0) { bf16x4 o; for (int k = 0; k < 4; ++k) o[k] = (bf16_t)p[k]; *reinterpret_cast<bf16x4*>((bf16_t*)j.shadow + i) = o; }
+            if (j.shadow_kind == 0) { h16x4 o; for (int k = 0; k < 4; ++k) o[k] = (h16_t)p[k]; *reinterpret_cast<h16x4*>((h16_t*)j.shadow + i) = o; }
             else *reinterpret_cast<f32x4*>((float*)j.shadow + i) = p;
         }
     }
@@ -290,22 +297,35 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
         const float v = beta2 * j.exp_avg_sq[i] + (1.f - beta2) * g * g;
         p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
         j.param[i] = p; j.exp_avg[i] = m; j.exp_avg_sq[i] = v;
-        if (j.shadow) { if (j.shadow_kind == 0) ((bf16_t*)j.shadow)[i] = (bf16_t)p; else ((float*)j.shadow)[i] = p; }
+        if (j.shadow) { if (j.shadow_kind == 0) ((h16_t*)j.shadow)[i] = (h16_t)p; else ((float*)j.shadow)[i] = p; }
     }
 }
 
+// GradScaler._amp_update_scale_ semantics on the device (one thread): amp = {scale, growth_tracker, found_inf of this step}.
+__global__ void amp_update_kernel(float* __restrict__ amp, const float* __restrict__ norm2, float growth, float backoff, int interval) {
+    const bool found = !isfinite(norm2[0]);
+    float scale = amp[0], tracker = amp[1];
+    if (found) { scale *= backoff; tracker = 0.f; }
+    else { tracker += 1.f; if (tracker >= (float)interval) { scale *= growth; tracker = 0.f; } }
+    amp[0] = scale; amp[1] = tracker; amp[2] = found ? 1.f : 0.f;
+}
+// device-side step count of a parameter group ({lr, step}): advances unless this step's gradients were non-finite
+__global__ void opt_advance_kernel(float* __restrict__ hyper, const float* __restrict__ norm2) {
+    if (!norm2 || isfinite(norm2[0])) hyper[1] += 1.f;
+}
+
 // ---- nn.Bilinear as a GEMM: z[b, i*D2 + j] = x1[b,i] * x2[b,j] (bf16 operand of y = z W^T), and the contraction of dz back ----
-__global__ void outer_bf16_kernel(const float* __restrict__ x1, const float* __restrict__ x2, bf16_t* __restrict__ z, int B, int D1, int D2) {
+__global__ void outer_bf16_kernel(const float* __restrict__ x1, const float* __restrict__ x2, h16_t* __restrict__ z, int B, int D1, int D2) {
     const size_t n = (size_t)B * D1 * D2 / 4, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
         const size_t e = q * 4;
         const int j = (int)(e % D2), i = (int)((e / D2) % D1), b = (int)(e / ((size_t)D1 * D2));
         const float a = x1[(size_t)b * D1 + i];
         const f32x4 v = *reinterpret_cast<const f32x4*>(x2 + (size_t)b * D2 + j);
-        bf16x4 o;
+        h16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(a * v[r]);
-        *reinterpret_cast<bf16x4*>(z + e) = o;
+        for (int r = 0; r < 4; ++r) o[r] = (h16_t)(a * v[r]);
+        *reinterpret_cast<h16x4*>(z + e) = o;
     }
 }
 // dx1[b,i] = sum_j dz[b,i,j] x2[b,j]: one wave per (b,i) row of dz
@@ -335,11 +355,12 @@ __global__ void outer_bwd_x2_kernel(const float* __restrict__ dz, const float* _
 
 extern "C" {
 
-int vqa_abi_version(void) { return 1; }
+int vqa_abi_version(void) { return 2; }
+int vqa_half_kind(void) { return VQA_HALF_KIND; }
 int vqa_outer_bf16(const float* x1, const float* x2, void* z_bf16, int B, int D1, int D2, vqa_stream_t s) {
     if (!x1 || !x2 || !z_bf16 || B <= 0 || D1 <= 0 || D2 <= 0 || D2 % 4) return VQA_ERR_ARG;
     const size_t n4 = (size_t)B * D1 * D2 / 4;
-    hipLaunchKernelGGL(outer_bf16_kernel, dim3(grid_for(n4)), dim3(TPB), 0, (hipStream_t)s, x1, x2, (bf16_t*)z_bf16, B, D1, D2);
+    hipLaunchKernelGGL(outer_bf16_kernel, dim3(grid_for(n4)), dim3(TPB), 0, (hipStream_t)s, x1, x2, (h16_t*)z_bf16, B, D1, D2);
     return (int)hipGetLastError();
 }
 int vqa_outer_bwd(const float* dz, const float* x1, const float* x2, float* dx1, float* dx2, int B, int D1, int D2, vqa_stream_t s) {
@@ -360,10 +381,21 @@ int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
 
 int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, const float* norm2, float max_norm, float lr,
                     float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* hyper_dev,
-                    float grad_prescale, vqa_stream_t s) {
+                    float grad_prescale, const float* amp_dev, vqa_stream_t s) {
     if (!jobs_dev || !chunks_dev || nchunks <= 0) return VQA_ERR_ARG;
+    if (amp_dev && !norm2) return VQA_ERR_ARG;            // the inf check rides on the norm
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(TPB), 0, (hipStream_t)s, jobs_dev, chunks_dev, norm2, max_norm, lr, beta1, beta2,
-                       eps, bias_correction1, bias_correction2, hyper_dev, grad_prescale == 0.f ? 1.f : grad_prescale);
+                       eps, bias_correction1, bias_correction2, hyper_dev, grad_prescale == 0.f ? 1.f : grad_prescale, amp_dev);
+    return (int)hipGetLastError();
+}
+int vqa_amp_update(float* amp_dev, const float* norm2, float growth_factor, float backoff_factor, int growth_interval, vqa_stream_t s) {
+    if (!amp_dev || !norm2 || growth_interval < 1) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, amp_dev, norm2, growth_factor, backoff_factor, growth_interval);
+    return (int)hipGetLastError();
+}
+int vqa_opt_advance(float* hyper_dev, const float* norm2, vqa_stream_t s) {
+    if (!hyper_dev) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, hyper_dev, norm2);
     return (int)hipGetLastError();
 }
 
@@ -371,14 +403,14 @@ int vqa_cast_f32_bf16(const float* src, void* dst, size_t n, vqa_stream_t s) {
     if (!src || !dst) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
     if (((uintptr_t)src | (uintptr_t)dst) & 15) return VQA_ERR_ARG;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(TPB), 0, (hipStream_t)s, src, (bf16_t*)dst, n);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(TPB), 0, (hipStream_t)s, src, (h16_t*)dst, n);
     return (int)hipGetLastError();
 }
 
 int vqa_cast_bf16_f32(const void* src, float* dst, size_t n, vqa_stream_t s) {
     if (!src || !dst) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)s, (const bf16_t*)src, dst, n);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)s, (const h16_t*)src, dst, n);
     return (int)hipGetLastError();
 }
 
@@ -391,7 +423,7 @@ int vqa_cast_multi(const VqaCastJob* jobs_dev, int njobs, uint64_t max_n, vqa_st
 }
 
 int vqa_colsum_bf16(const void* x, int M, int N, int ld, float* out, vqa_stream_t s) {
-    return colsum_launch<bf16_t>((const bf16_t*)x, M, N, ld, out, (hipStream_t)s);
+    return colsum_launch<h16_t>((const h16_t*)x, M, N, ld, out, (hipStream_t)s);
 }
 int vqa_colsum_f32(const float* x, int M, int N, int ld, float* out, vqa_stream_t s) {
     return colsum_launch<float>(x, M, N, ld, out, (hipStream_t)s);
@@ -400,7 +432,7 @@ int vqa_colsum_f32(const float* x, int M, int N, int ld, float* out, vqa_stream_
 int vqa_add_f32(const float* a, const float* b, float* y, void* y_bf16, size_t n, vqa_stream_t s) {
     if (!a || !b || (!y && !y_bf16) || n % 4) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
-    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)s, a, b, y, (bf16_t*)y_bf16, n);
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, (hipStream_t)s, a, b, y, (h16_t*)y_bf16, n);
     return (int)hipGetLastError();
 }
 
@@ -408,14 +440,14 @@ int vqa_gather_rows_f32(const float* src, const int32_t* idx, float* dst, void* 
     if (!src || !idx || (!dst && !dst_bf16) || D % 4 || ld_src % 4 || n < 0) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n * D / 4)), dim3(TPB), 0, (hipStream_t)s, src, idx, dst,
-                       (bf16_t*)dst_bf16, n, D, ld_src);
+                       (h16_t*)dst_bf16, n, D, ld_src);
     return (int)hipGetLastError();
 }
 
 int vqa_patchify_bf16(const float* pixels, void* out, int B, int C, int H, int W, int ps, vqa_stream_t s) {
     if (!pixels || !out || B <= 0 || ps % 4 || H % ps || W % ps || W % 4) return VQA_ERR_ARG;
     const size_t total = (size_t)B * C * H * W / 4;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)s, pixels, (bf16_t*)out, B, C, H, W, ps);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)s, pixels, (h16_t*)out, B, C, H, W, ps);
     return (int)hipGetLastError();
 }
 
@@ -427,7 +459,7 @@ int vqa_clip_assemble(const float* E, const float* cls, const float* pos, float*
 
 int vqa_clip_assemble_bwd(const float* du, void* dE_bf16, float* dcls, float* dpos, int B, int P, int D, vqa_stream_t s) {
     if (!du || !dE_bf16 || !dcls || !dpos) return VQA_ERR_ARG;
-    hipLaunchKernelGGL(clip_assemble_bwd_kernel, dim3(P + 1, ceil_div(D, 256)), dim3(256), 0, (hipStream_t)s, du, (bf16_t*)dE_bf16, dcls, dpos, B, P, D);
+    hipLaunchKernelGGL(clip_assemble_bwd_kernel, dim3(P + 1, ceil_div(D, 256)), dim3(256), 0, (hipStream_t)s, du, (h16_t*)dE_bf16, dcls, dpos, B, P, D);
     return (int)hipGetLastError();
 }
 
@@ -435,8 +467,8 @@ int vqa_act_drop_bwd(const float* dy, const void* pre_bf16, int act, float* out,
                      uint32_t stream, vqa_stream_t s) {
     if (!dy || (!out && !out_bf16) || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
-    hipLaunchKernelGGL(act_drop_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)s, dy, (const bf16_t*)pre_bf16, act, out,
-                       (bf16_t*)out_bf16, n, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
+    hipLaunchKernelGGL(act_drop_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)s, dy, (const h16_t*)pre_bf16, act, out,
+                       (h16_t*)out_bf16, n, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
     return (int)hipGetLastError();
 }
 

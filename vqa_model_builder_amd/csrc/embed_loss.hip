@@ -8,9 +8,11 @@ namespace {
 // gridDim = (B, chunks): every block of a sample redoes the (cheap) pad-aware position-id scan over its S <= 4096 tokens -- block
 // (b, 0) also writes the ids out -- and gathers its share of the rows: u[b,s,:] = word[ids] + pos[pos_id] + type0.  One block
 // per sample left 32 workgroups to pull 6 MB of random table rows (49 us); 8 chunks per sample: 256 workgroups.
+// Ids outside [0, V) and position ids >= Pmax (nn.Embedding raises / device-asserts on them) are never dereferenced: the row reads
+// the padding row instead and *ok (optional device word, 1 = fine) is cleared for the host (hip/ops.py: check_device_status).
 __global__ void roberta_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
                                          const float* __restrict__ type0, int32_t* __restrict__ pos_ids, float* __restrict__ u,
-                                         int S, int D, int pad_id) {
+                                         int S, int D, int pad_id, int V, int Pmax, int32_t* __restrict__ ok) {
     extern __shared__ int scan[];                 // [S]
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int s = tid; s < S; s += blockDim.x) scan[s] = ids[(size_t)b * S + s] != pad_id ? 1 : 0;
@@ -23,9 +25,11 @@ __global__ void roberta_embed_fwd_kernel(const int64_t* __restrict__ ids, const 
     const int per = (S + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = min(S, s0 + per);
     for (int t = tid; t < (s1 - s0) * d4; t += blockDim.x) {
         const int s = s0 + t / d4, c = t % d4;
-        const int64_t id = ids[(size_t)b * S + s];
+        int64_t id = ids[(size_t)b * S + s];
+        int pid = scan[s];
+        if (id < 0 || id >= V || pid >= Pmax) { if (ok && c == 0) *ok = 0; id = id < 0 || id >= V ? pad_id : id; pid = pid >= Pmax ? pad_id : pid; }
         f32x4 v = reinterpret_cast<const f32x4*>(word + (size_t)id * D)[c];
-        v += reinterpret_cast<const f32x4*>(pos + (size_t)scan[s] * D)[c];
+        v += reinterpret_cast<const f32x4*>(pos + (size_t)pid * D)[c];
         v += reinterpret_cast<const f32x4*>(type0)[c];
         reinterpret_cast<f32x4*>(u + ((size_t)b * S + s) * D)[c] = v;
     }
@@ -33,21 +37,22 @@ __global__ void roberta_embed_fwd_kernel(const int64_t* __restrict__ ids, const 
 
 // scatter-add rows of du into the (pre-zeroed) dense table gradients; pad rows are skipped (padding_idx)
 __global__ void roberta_embed_bwd_kernel(const float* __restrict__ du, const int64_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
-                                         float* __restrict__ dword, float* __restrict__ dpos, int rows, int D, int pad_id) {
+                                         float* __restrict__ dword, float* __restrict__ dpos, int rows, int D, int pad_id, int V, int Pmax) {
     const size_t total = (size_t)rows * D, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int r = (int)(t / D), d = (int)(t % D);
         const float g = du[t];
         const int64_t id = ids[r];
         const int pid = pos_ids[r];
-        if (id != pad_id) atomicAdd(dword + (size_t)id * D + d, g);
-        if (pid != pad_id) atomicAdd(dpos + (size_t)pid * D + d, g);
+        if (id != pad_id && id >= 0 && id < V) atomicAdd(dword + (size_t)id * D + d, g);
+        if (pid != pad_id && pid < Pmax) atomicAdd(dpos + (size_t)pid * D + d, g);
     }
 }
 
 // ---- cross entropy: one 256-thread block per row (a wave per row walked the 3000 classes in 47 dependent steps, twice: 23 us) ----
+constexpr int64_t VQA_IGNORE_INDEX = -100;
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
-                              int64_t* __restrict__ argmax, float* __restrict__ lse_out, int B, int C) {
+                              int64_t* __restrict__ argmax, float* __restrict__ lse_out, int B, int C, int32_t* __restrict__ ok) {
     __shared__ float sm[4]; __shared__ int si[4]; __shared__ float ss[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x;
     const float* x = logits + (size_t)row * ld;
@@ -75,28 +80,45 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         const float lse = m + __logf(ss[0] + ss[1] + ss[2] + ss[3]);
         if (lse_out) lse_out[row] = lse;
         if (argmax) argmax[row] = mi;
-        if (row_loss) row_loss[row] = labels ? lse - x[labels[row]] : 0.f;
+        if (row_loss) {
+            // F.cross_entropy semantics: label == ignore_index (-100) contributes nothing and is not counted by the mean; any
+            // other label outside [0, C) (torch: device assert) is never dereferenced -- the row's loss becomes NaN so the
+            // fault is visible in the loss, and *ok is cleared
+            float l = 0.f;
+            if (labels) {
+                const int64_t y = labels[row];
+                if (y >= 0 && y < C) l = lse - x[y];
+                else if (y != VQA_IGNORE_INDEX) { l = __builtin_nanf(""); if (ok) *ok = 0; }
+            }
+            row_loss[row] = l;
+        }
     }
 }
 
-__global__ void ce_mean_kernel(const float* __restrict__ row_loss, float* __restrict__ loss_mean, int B) {
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < B; i += 64) acc += row_loss[i];
-    acc = wave_sum(acc);
-    if (threadIdx.x == 0) loss_mean[0] = acc / B;
+// mean over the rows whose label is not ignore_index (0 valid rows: 0/0 = NaN, as torch)
+__global__ void ce_mean_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, float* __restrict__ loss_mean, int B) {
+    float acc = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < B; i += 64) { acc += row_loss[i]; cnt += labels[i] != VQA_IGNORE_INDEX ? 1.f : 0.f; }
+    acc = wave_sum(acc); cnt = wave_sum(cnt);
+    if (threadIdx.x == 0) { loss_mean[0] = acc / cnt; loss_mean[1] = cnt; }
 }
 
 __global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels, const float* __restrict__ lse,
-                              const float* __restrict__ dloss, float* __restrict__ dlogits, bf16_t* __restrict__ dlb, int B, int C) {
-    const float scale = dloss[0] / B;
+                              const float* __restrict__ dloss, const float* __restrict__ nvalid, float* __restrict__ dlogits, h16_t* __restrict__ dlb,
+                              int B, int C) {
+    const float scale = dloss[0] / (nvalid ? nvalid[0] : (float)B);
     const size_t total = (size_t)B * C, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int r = (int)(t / C), c = (int)(t % C);
-        float g = __expf(logits[(size_t)r * ld + c] - lse[r]);
-        if (labels[r] == c) g -= 1.f;
-        g *= scale;
+        const int64_t y = labels[r];
+        float g = 0.f;
+        if (y >= 0 && y < C) {                               // ignored / invalid rows get no gradient
+            g = __expf(logits[(size_t)r * ld + c] - lse[r]);
+            if (y == c) g -= 1.f;
+            g *= scale;
+        }
         if (dlogits) dlogits[t] = g;
-        if (dlb) dlb[t] = (bf16_t)g;
+        if (dlb) dlb[t] = (h16_t)g;
     }
 }
 
@@ -105,42 +127,44 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const in
 extern "C" {
 
 int vqa_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, int32_t* pos_ids, float* u,
-                          int B, int S, int D, int pad_id, vqa_stream_t s) {
+                          int B, int S, int D, int pad_id, int V, int Pmax, int32_t* ok, vqa_stream_t s) {
     if (!ids || !word || !pos || !type0 || !pos_ids || !u || B <= 0 || S <= 0 || S > 4096 || D % 4) return VQA_ERR_ARG;
+    if (V <= pad_id || Pmax <= pad_id || pad_id < 0) return VQA_ERR_ARG;
     const int chunks = S >= 64 ? 8 : S >= 8 ? 2 : 1;
-    hipLaunchKernelGGL(roberta_embed_fwd_kernel, dim3(B, chunks), dim3(256), (size_t)S * 4, (hipStream_t)s, ids, word, pos, type0, pos_ids, u, S, D, pad_id);
+    hipLaunchKernelGGL(roberta_embed_fwd_kernel, dim3(B, chunks), dim3(256), (size_t)S * 4, (hipStream_t)s, ids, word, pos, type0, pos_ids, u, S, D, pad_id,
+                       V, Pmax, ok);
     return (int)hipGetLastError();
 }
 
 int vqa_roberta_embed_bwd(const float* du, const int64_t* ids, const int32_t* pos_ids, float* dword, float* dpos, float* dtype0,
-                          int B, int S, int D, int pad_id, vqa_stream_t s) {
+                          int B, int S, int D, int pad_id, int V, int Pmax, vqa_stream_t s) {
     if (!du || !ids || !pos_ids || !dword || !dpos || !dtype0) return VQA_ERR_ARG;
     const size_t total = (size_t)B * S * D;
     size_t g = (total + 255) / 256; if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(roberta_embed_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, du, ids, pos_ids, dword, dpos, B * S, D, pad_id);
+    hipLaunchKernelGGL(roberta_embed_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, du, ids, pos_ids, dword, dpos, B * S, D, pad_id, V, Pmax);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     return vqa_colsum_f32(du, B * S, D, D, dtype0, s);
 }
 
 int vqa_softmax_ce_argmax_fwd(const float* logits, int ld, const int64_t* labels, float* row_loss, float* loss_mean, int64_t* argmax,
-                              float* lse, int B, int C, vqa_stream_t s) {
+                              float* lse, int B, int C, int32_t* ok, vqa_stream_t s) {
     if (!logits || B <= 0 || C <= 0 || (loss_mean && !row_loss)) return VQA_ERR_ARG;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, logits, ld, labels, row_loss, argmax, lse, B, C);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, logits, ld, labels, row_loss, argmax, lse, B, C, ok);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (loss_mean && labels) {
-        hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, row_loss, loss_mean, B);
+        hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, row_loss, labels, loss_mean, B);
         e = hipGetLastError();
     }
     return (int)e;
 }
 
-int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss, float* dlogits,
-                       void* dlogits_bf16, int B, int C, vqa_stream_t s) {
+int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss, const float* nvalid,
+                       float* dlogits, void* dlogits_bf16, int B, int C, vqa_stream_t s) {
     if (!logits || !labels || !lse || !dloss || (!dlogits && !dlogits_bf16)) return VQA_ERR_ARG;
     size_t g = ((size_t)B * C + 255) / 256; if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, logits, ld, labels, lse, dloss, dlogits, (bf16_t*)dlogits_bf16, B, C);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, logits, ld, labels, lse, dloss, nvalid, dlogits, (h16_t*)dlogits_bf16, B, C);
     return (int)hipGetLastError();
 }
 

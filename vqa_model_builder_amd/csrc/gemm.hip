@@ -18,21 +18,42 @@
 // split-K (gridDim.z > 1) accumulates fp32 partials with global_atomic_add_f32 into a pre-zeroed C.
 #include "common.h"
 #include "vqa_hip.h"
+#include <hip/hip_ext.h>
+#include <vector>
 
 namespace {
+
+// ---- launch + optional kernel-timestamp profiling -------------------------------------------------------------------
+// With profiling on (vqa_gemm_profile), every GEMM dispatch goes through hipExtLaunchKernel with a start / stop event pair:
+// the events receive the kernel's own begin / end timestamps from its dispatch packet -- the quantity rocprofv3
+// --kernel-trace reports -- so bench.py's roofline numbers are rocprof-equivalent without a profiler attached (an ordinary
+// hipEventRecord bracket adds ~3 us of host / queue latency per launch).  Off (default): a plain launch, nothing recorded.
+struct ProfRec { hipEvent_t a, b; double flop; int tag; };
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+int g_prof_tag = 0;
+
+template <class Kern, class Arg>
+inline void vqa_launch(Kern kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const Arg& arg, double flop) {
+    if (!g_prof_on) { hipLaunchKernelGGL(kern, grid, block, lds, st, arg); return; }
+    ProfRec r{nullptr, nullptr, flop, g_prof_tag};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { hipLaunchKernelGGL(kern, grid, block, lds, st, arg); return; }
+    hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, r.a, r.b, 0, arg);
+    g_prof.push_back(r);
+}
 
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 
 struct GemmArgs {
-    const bf16_t* a; const bf16_t* b;
+    const h16_t* a; const h16_t* b;
     int M, N, K, lda, ldb;
     float* c_f32; int ldc_f32;
-    bf16_t* c_bf16; int ldc_bf16;
-    bf16_t* pre_bf16; int ld_pre;          // pre-activation save
+    h16_t* c_bf16; int ldc_bf16;
+    h16_t* pre_bf16; int ld_pre;          // pre-activation save
     const float* bias;                      // [N]
     const float* residual; int ld_res;      // fp32 [M,N]
-    const bf16_t* act_grad_of; int ld_ag;   // multiply by act'(this) (backward through an activation)
+    const h16_t* act_grad_of; int ld_ag;   // multiply by act'(this) (backward through an activation)
     int act;                                // activation applied in the epilogue (forward)
     int act_bwd_kind;                       // activation whose derivative is applied (backward)
     float alpha;
@@ -72,7 +93,7 @@ struct Stage {
     u32x4 v[PT];
 
     // R = number of valid rows (M or N), Kend = end of this split's k range
-    __device__ __forceinline__ void load(const bf16_t* __restrict__ g, int ld, int row0, int R, int k0, int Kend, int tid) {
+    __device__ __forceinline__ void load(const h16_t* __restrict__ g, int ld, int row0, int R, int k0, int Kend, int tid) {
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int c = tid + i * NTHREADS;
@@ -110,10 +131,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // fragment of 16 rows (r0..r0+15) x 32 k (substep s) for lane: rows on lane&15, k = 8*(lane>>4)+j
 template <int ROWS, bool KC, bool USE_TR>
-__device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int lane) {
+__device__ __forceinline__ h16x8 load_frag(const char* lds, int r0, int s, int lane) {
     const int i = lane & 15, g = lane >> 4;
     if (KC) {
-        return *reinterpret_cast<const bf16x8*>(lds + kc_off(r0 + i, 4 * s + g));
+        return *reinterpret_cast<const h16x8*>(lds + kc_off(r0 + i, 4 * s + g));
     } else if (USE_TR) {
         // lane 4q+p of each 16-lane group addresses k-row q, columns 4p..4p+3 of the 4(k) x 16(r) block;
         // it receives column i: element j = k-row j.
@@ -124,12 +145,12 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds, int r0, int s, int 
         const int o1 = rc_off<ROWS>(krow + 4, col >> 3) + ((col & 7) << 1);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + o1));
-        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        union { struct { s16x4 a, b; } s; h16x8 v; } u;
         u.s.a = lo; u.s.b = hi;
         return u.v;
     } else {
         // portable fallback (no transposing read): 8 scalar 16-bit LDS reads
-        union { unsigned short h[8]; bf16x8 v; } u;
+        union { unsigned short h[8]; h16x8 v; } u;
         const int col = r0 + i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -234,15 +255,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             if (m >= p.M || !nok) continue;
             v += bv;
             if (p.act_grad_of) {
-                const bf16x4 pv = *reinterpret_cast<const bf16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+                const h16x4 pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
             }
             if (p.pre_bf16) {
-                bf16x4 o;
+                h16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+                for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+                *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
             }
             if (p.act != ACT_NONE) {
 #pragma unroll
@@ -253,10 +274,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
             if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
             if (p.c_bf16) {
-                bf16x4 o;
+                h16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+                for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+                *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
             }
         }
         __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p_in) {
         const char* lb = la + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 fa[TM], fb[TN];
+            h16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = load_frag<BM, A_KC, USE_TR>(la, wm * WTM + 16 * i, s, lane);
 #pragma unroll
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p_in) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = VQA_MFMA16(fb[j], fa[i], acc[i][j]);
         }
         if (more) {
             sa.store(smem + (cur ^ 1) * BUF_BYTES, tid);
@@ -378,7 +399,7 @@ struct DmaLane {
 };
 
 template <int ROWS, bool KC, int BKT, int NW>
-__device__ __forceinline__ void dma_init(DmaLane (&d)[ROWS * (BKT / 8) / 64 / NW], const bf16_t* __restrict__ g, int ld, int row0, int R,
+__device__ __forceinline__ void dma_init(DmaLane (&d)[ROWS * (BKT / 8) / 64 / NW], const h16_t* __restrict__ g, int ld, int row0, int R,
                                          int kbeg, int kend, int wave, int lane) {
     constexpr int PER_WAVE = ROWS * (BKT / 8) / 64 / NW;
     constexpr int CPK = BKT / 8;                                  // 16-B chunks per k-contiguous row
@@ -442,19 +463,19 @@ __device__ __forceinline__ void frag_offsets(int (&o0)[NT], int (&o1)[NT], int r
 // whatever its depth).  The asm reads are invisible to the compiler's counters, so the caller closes each group with
 // frag_fence(): s_waitcnt lgkmcnt(0) plus a register dependency that keeps the MFMAs behind it.
 template <int ROWS, bool KC>
-__device__ __forceinline__ bf16x8 load_frag1(const char* lds, int o0, int o1, int s) {
-    if (KC) return *reinterpret_cast<const bf16x8*>(lds + (s ? o1 : o0));
+__device__ __forceinline__ h16x8 load_frag1(const char* lds, int o0, int o1, int s) {
+    if (KC) return *reinterpret_cast<const h16x8*>(lds + (s ? o1 : o0));
     constexpr int SUB = 32 * ROWS * 2;
     const unsigned base = (unsigned)(uintptr_t)lds + s * SUB;       // low 32 bits of a flat LDS address = LDS byte offset
     s16x4 lo, hi;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(base + o0));
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(base + o1));
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    union { struct { s16x4 a, b; } s; h16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
 }
 template <bool ANY_RC, int NA, int NB>
-__device__ __forceinline__ void frag_fence(bf16x8 (&fa)[NA], bf16x8 (&fb)[NB]) {
+__device__ __forceinline__ void frag_fence(h16x8 (&fa)[NA], h16x8 (&fb)[NB]) {
     if (!ANY_RC) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -535,7 +556,7 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
                 const char* lb = la + A_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < BKT / 32; ++ks) {
-                    bf16x8 fa[TM], fb[TN];
+                    h16x8 fa[TM], fb[TN];
 #pragma unroll
                     for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, ao0[i], ao1[i], ks);
 #pragma unroll
@@ -545,7 +566,7 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = VQA_MFMA16(fb[j], fa[i], acc[i][j]);
                 }
             }
         }
@@ -586,7 +607,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
 // of a backward pass: nothing waits for them, so they are queued and issued together).  One launch pays one cold start and
 // one tail for all of them, and thousands of equal-cost tiles balance over the CUs where a single 768 x 768 output has 144.
 constexpr int MAX_GROUP = 32;
-struct GroupItem { const bf16_t* a; const bf16_t* b; float* c; int M, N, K, lda, ldb, ldc; };
+struct GroupItem { const h16_t* a; const h16_t* b; float* c; int M, N, K, lda, ldb, ldc; };
 struct GroupArgs { int n; int group_m; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
@@ -624,7 +645,7 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int grid = tiles;
     if (g_grid_cap > 0 && splits == 1 && tiles > g_grid_cap) grid = g_grid_cap / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p);
+    vqa_launch(kern, dim3(grid, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p, 2.0 * p.M * p.N * p.K);
     return (int)hipGetLastError();
 }
 template <int BM, int BN, int WM_, int WN_, int BKT, int ST>
@@ -653,7 +674,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     dim3 grid(tiles, 1, splits), block(NTHREADS);
-#define VQA_LAUNCH(AK, BKC, TR) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, AK, BKC, TR>), grid, block, 0, st, p)
+#define VQA_LAUNCH(AK, BKC, TR) vqa_launch(gemm_kernel<BM, BN, WM, WN, AK, BKC, TR>, grid, block, 0, st, p, 2.0 * p.M * p.N * p.K)
     if (a_kc && b_kc) VQA_LAUNCH(true, true, true);
     else if (a_kc && !b_kc) { if (g_use_tr) VQA_LAUNCH(true, false, true); else VQA_LAUNCH(true, false, false); }
     else if (!a_kc && !b_kc) { if (g_use_tr) VQA_LAUNCH(false, false, true); else VQA_LAUNCH(false, false, false); }
@@ -664,6 +685,21 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 
 }  // namespace
 
+extern "C" void vqa_gemm_profile(int on, int tag) { g_prof_on = on != 0; g_prof_tag = tag; }
+extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches) {
+    for (int t = 0; t < ntags; ++t) { flop[t] = 0.0; ms[t] = 0.0; launches[t] = 0; }
+    int rc = 0;
+    for (ProfRec& r : g_prof) {
+        float e = 0.f;
+        hipError_t err = hipEventSynchronize(r.b);
+        if (err == hipSuccess) err = hipEventElapsedTime(&e, r.a, r.b);
+        if (err != hipSuccess) rc = (int)err;
+        else if (r.tag >= 0 && r.tag < ntags) { flop[r.tag] += r.flop; ms[r.tag] += e; launches[r.tag] += 1; }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return rc;
+}
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_group_m(int g) { g_group_m = g; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
@@ -690,13 +726,13 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     if (!d->c_f32 && !d->c_bf16 && !d->pre_bf16) return VQA_ERR_ARG;
 
     GemmArgs p;
-    p.a = (const bf16_t*)d->a; p.b = (const bf16_t*)d->b;
+    p.a = (const h16_t*)d->a; p.b = (const h16_t*)d->b;
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb;
     p.c_f32 = d->c_f32; p.ldc_f32 = d->ldc_f32;
-    p.c_bf16 = (bf16_t*)d->c_bf16; p.ldc_bf16 = d->ldc_bf16;
-    p.pre_bf16 = (bf16_t*)d->pre_bf16; p.ld_pre = d->ld_pre;
+    p.c_bf16 = (h16_t*)d->c_bf16; p.ldc_bf16 = d->ldc_bf16;
+    p.pre_bf16 = (h16_t*)d->pre_bf16; p.ld_pre = d->ld_pre;
     p.bias = d->bias; p.residual = d->residual; p.ld_res = d->ld_res;
-    p.act_grad_of = (const bf16_t*)d->act_grad_of; p.ld_ag = d->ld_ag;
+    p.act_grad_of = (const h16_t*)d->act_grad_of; p.ld_ag = d->ld_ag;
     p.act = d->act; p.act_bwd_kind = d->act_bwd;
     p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
     p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
@@ -782,7 +818,9 @@ static int launch_grouped(const GroupArgs& g, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.tile_end[g.n - 1]), dim3(256), LDS, st, g);
+    double flop = 0.0;
+    for (int i = 0; i < g.n; ++i) flop += 2.0 * g.it[i].M * g.it[i].N * g.it[i].K;
+    vqa_launch(kern, dim3(g.tile_end[g.n - 1]), dim3(256), LDS, st, g, flop);
     return (int)hipGetLastError();
 }
 
@@ -816,7 +854,7 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
         tiles += (long)ceil_div(d.M, bm) * ceil_div(d.N, bn);
         if (tiles > 0x3fffffff) return VQA_ERR_ARG;
         g.tile_end[i] = (int)tiles;
-        g.it[i] = GroupItem{(const bf16_t*)d.a, (const bf16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc};
+        g.it[i] = GroupItem{(const h16_t*)d.a, (const h16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc};
     }
     // ring depth as for single launches: the third stage pays when k is long and the grid is under two workgroups per CU
     const bool deep = tile == 1 && kmin >= 2048 && tiles < 512;

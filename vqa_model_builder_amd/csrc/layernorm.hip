@@ -15,7 +15,7 @@ constexpr int MAXV = 16;                 // float4 per lane -> cols <= 64*4*16 =
 template <int NV>
 __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ y, bf16_t* __restrict__ yb, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    float* __restrict__ y, h16_t* __restrict__ yb, float* __restrict__ mean_out, float* __restrict__ rstd_out,
     int rows, int cols, float eps, float drop_p, float inv_keep, uint64_t seed, uint32_t stream) {
     if (drop_p > 0.f) seed = resolve_seed(seed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
                 for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
                 if (drop_p > 0.f) o *= dropout_scale4(seed, stream, (uint64_t)row * cols + 4 * c, drop_p, inv_keep);
                 if (y) reinterpret_cast<f32x4*>(y + (size_t)row * cols)[c] = o;
-                if (yb) { bf16x4 ob; for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)o[j]; reinterpret_cast<bf16x4*>(yb + (size_t)row * cols)[c] = ob; }
+                if (yb) { h16x4 ob; for (int j = 0; j < 4; ++j) ob[j] = (h16_t)o[j]; reinterpret_cast<h16x4*>(yb + (size_t)row * cols)[c] = ob; }
             }
         }
     }
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
 template <int NV>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx, bf16_t* __restrict__ dxb,
+    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx, h16_t* __restrict__ dxb,
     float* __restrict__ ws, int rows, int cols, float drop_p, float inv_keep, uint64_t seed, uint32_t stream, int drop_mode, int want_colsum,
     float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta, float* __restrict__ acc_colsum) {
     if (drop_p > 0.f) seed = resolve_seed(seed);
@@ -117,16 +117,16 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
                 if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * cols)[c];
                 if (dx) reinterpret_cast<f32x4*>(dx + (size_t)row * cols)[c] = o;
                 if (dxb || want_colsum) {
-                    bf16x4 ob;
+                    h16x4 ob;
                     f32x4 ks = {1.f, 1.f, 1.f, 1.f};
                     if (drop_mode == 1) ks = dropout_scale4(seed, stream, (uint64_t)row * cols + 4 * c, drop_p, inv_keep);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float t = o[j] * ks[j];
-                        ob[j] = (bf16_t)t;
+                        ob[j] = (h16_t)t;
                         cs[i][j] += t;                 // column sum of the (masked) gradient = bias gradient of the producer Linear
                     }
-                    if (dxb) reinterpret_cast<bf16x4*>(dxb + (size_t)row * cols)[c] = ob;
+                    if (dxb) reinterpret_cast<h16x4*>(dxb + (size_t)row * cols)[c] = ob;
                 }
             }
         }
@@ -235,7 +235,7 @@ int vqa_layernorm_fwd(const float* x, const float* add, const float* gamma, cons
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     const int nv = nv_for(cols);
 #define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)s, x, add, gamma, beta, \
-                                      y_f32, (bf16_t*)y_bf16, mean, rstd, rows, cols, eps, drop_p, inv_keep, drop_seed, drop_stream)
+                                      y_f32, (h16_t*)y_bf16, mean, rstd, rows, cols, eps, drop_p, inv_keep, drop_seed, drop_stream)
     if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4);
     else if (nv <= 8) LN_FWD(8); else LN_FWD(16);
 #undef LN_FWD
@@ -297,7 +297,7 @@ int vqa_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
     if (lds_bytes > 160 * 1024 - 256) return VQA_ERR_ARG;            // affine/colsum partials need 48*cols bytes of LDS: cols <= 3328
     const int nv = nv_for(cols);
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(grid), dim3(WAVES * 64), lds_bytes, (hipStream_t)s, dy, x, mean, rstd, \
-                                      gamma, dres, dx_f32, (bf16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode, dx_colsum ? 1 : 0, ag, ab, ac)
+                                      gamma, dres, dx_f32, (h16_t*)dx_bf16, wsp, rows, cols, drop_p, inv_keep, drop_seed, drop_stream, drop_mode, dx_colsum ? 1 : 0, ag, ab, ac)
     if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4);
     else if (nv <= 8) {
         static bool attr8 = false;       // 8 float4/lane: 96 KiB of LDS for the three-way cross-wave combine

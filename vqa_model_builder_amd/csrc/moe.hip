@@ -154,7 +154,7 @@ __global__ void scatter_add_kernel(const float* __restrict__ y, const int32_t* _
 
 // dy[i,:] = w_tok[list[i]] * dout[list[i],:] ;  dw_tok[list[i]] = <dout[list[i],:], y[i,:]>     one wave per i
 __global__ void combine_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ y, const int32_t* __restrict__ list,
-                                   const float* __restrict__ w_tok, float* __restrict__ dy, bf16_t* __restrict__ dyb,
+                                   const float* __restrict__ w_tok, float* __restrict__ dy, h16_t* __restrict__ dyb,
                                    float* __restrict__ dw_tok, int n, int D) {
     const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -165,7 +165,7 @@ __global__ void combine_bwd_kernel(const float* __restrict__ dout, const float* 
         const float g = dout[(size_t)tok * D + d];
         dot += g * y[(size_t)i * D + d];
         if (dy) dy[(size_t)i * D + d] = w * g;
-        if (dyb) dyb[(size_t)i * D + d] = (bf16_t)(w * g);
+        if (dyb) dyb[(size_t)i * D + d] = (h16_t)(w * g);
     }
     dot = wave_sum(dot);
     if (lane == 0) dw_tok[tok] = dot;
@@ -208,14 +208,14 @@ __global__ void randn_kernel(float* __restrict__ out, uint64_t n, uint64_t seed,
     }
 }
 
-__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ yb, uint64_t n, float p, float inv_keep,
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, h16_t* __restrict__ yb, uint64_t n, float p, float inv_keep,
                                uint64_t seed, uint32_t stream) {
     if (p > 0.f) seed = resolve_seed(seed);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float v = x[i] * (p > 0.f ? dropout_scale(seed, stream, i, p, inv_keep) : 1.f);
         if (y) y[i] = v;
-        if (yb) yb[i] = (bf16_t)v;
+        if (yb) yb[i] = (h16_t)v;
     }
 }
 
@@ -276,7 +276,7 @@ int vqa_moe_combine_bwd(const float* dout, const float* y, const int32_t* list, 
                         float* dw_tok, int n, int D, vqa_stream_t s) {
     if (!dout || !y || !list || !w_tok || !dw_tok || (!dy && !dy_bf16)) return VQA_ERR_ARG;
     if (n <= 0) return VQA_OK;
-    hipLaunchKernelGGL(combine_bwd_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, (hipStream_t)s, dout, y, list, w_tok, dy, (bf16_t*)dy_bf16, dw_tok, n, D);
+    hipLaunchKernelGGL(combine_bwd_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, (hipStream_t)s, dout, y, list, w_tok, dy, (h16_t*)dy_bf16, dw_tok, n, D);
     return (int)hipGetLastError();
 }
 
@@ -298,7 +298,7 @@ int vqa_dropout_f32(const float* x, float* y, void* y_bf16, uint64_t n, float p,
     if (!x || (!y && !y_bf16) || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
     size_t g = (n + 255) / 256; if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(dropout_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, x, y, (bf16_t*)y_bf16, n, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
+    hipLaunchKernelGGL(dropout_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, x, y, (h16_t*)y_bf16, n, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
     return (int)hipGetLastError();
 }
 

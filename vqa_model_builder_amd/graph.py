@@ -89,7 +89,8 @@ class GraphedTrainStep:
         try:
             out = self.model(**self.static)
             loss = self.loss_of(out)
-            loss.backward()
+            # fp16 mode: the optimiser's device-side loss scale (GradScaler's role) multiplies the loss inside the capture
+            (self.opt.scale_loss(loss) if hasattr(self.opt, 'scale_loss') else loss).backward()
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer

@@ -14,7 +14,7 @@ import torch
 from . import kernels as K
 from .kernels import Drop, NO_DROP
 
-F32, BF16 = torch.float32, torch.bfloat16
+F32 = torch.float32
 
 
 _rng_epoch = None       # device int64 word behind INDIRECT seeds (HIP-graph mode), see csrc/common.h resolve_seed
@@ -149,7 +149,7 @@ class ClipRunner:
                                               dgamma=G[k + 'ln2.w'], dbeta=G[k + 'ln2.b'], dx_colsum=G[k + 'out_b'], defer=True)
             K.linear_dw(dx1b, ctx, M, D, D, out=G[k + 'out_w'], prezeroed=False)
             _, dctx = K.linear_dx(dx1b, W.s(k + 'out_w'), M, D, D, want_bf16=True)
-            dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dx.device)
+            dqkv = torch.empty((M, 3 * D), dtype=K.HALF(), device=dx.device)
             qb = G[k + 'qkv_b']
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, T, T, D // H,
                             dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D,
@@ -229,7 +229,7 @@ class RobertaRunner:
                                               dgamma=G[k + 'ao_ln.w'], dbeta=G[k + 'ao_ln.b'], dx_colsum=G[k + 'ao_b'], defer=True)
             K.linear_dw(ds1b, ctx, M, D, D, out=G[k + 'ao_w'], prezeroed=False)
             _, dctx = K.linear_dx(ds1b, W.s(k + 'ao_w'), M, D, D, want_bf16=True)
-            dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+            dqkv = torch.empty((M, 3 * D), dtype=K.HALF(), device=dev)
             qb = G[k + 'qkv_b']
             K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, S, S, D // H,
                             dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, kpm, Drop(pa, seed, st),
@@ -312,8 +312,8 @@ class CrossModalAttentionRunner:
                                           dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'], defer=True)
         K.linear_dw(ds2b, S['ctx2'], M, D, D, out=G['ca_out_w'], prezeroed=False)
         _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), M, D, D, want_bf16=True)
-        dq2 = torch.empty((M, D), dtype=BF16, device=dev)
-        dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
+        dq2 = torch.empty((M, D), dtype=K.HALF(), device=dev)
+        dkv2 = torch.empty((Mv, 2 * D), dtype=K.HALF(), device=dev)
         kv2 = S['kv2']
         K.attention_bwd(S['q2'], kv2[:, :D], kv2[:, D:], dctx2, D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, dq2, dkv2[:, :D], dkv2[:, D:],
                         D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3),
@@ -332,7 +332,7 @@ class CrossModalAttentionRunner:
         K.linear_dw(ds1b, S['ctx'], M, D, D, out=G['sa_out_w'], prezeroed=False)
         _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), M, D, D, want_bf16=True)
         qkv = S['qkv']
-        dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+        dqkv = torch.empty((M, 3 * D), dtype=K.HALF(), device=dev)
         K.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], dctx, 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh,
                         dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, S['qm'], Drop(pd, seed, 1),
                         dq_colsum=G['sa_in_b'][:D], dk_colsum=G['sa_in_b'][D:2 * D], dv_colsum=G['sa_in_b'][2 * D:])
@@ -403,8 +403,8 @@ class CrossModalAttentionRunner:
                                           dgamma=G['n2.w'], dbeta=G['n2.b'], dx_colsum=G['ca_out_b'], defer=True)
         K.linear_dw(ds2b, S['ctx2'], B, D, D, out=G['ca_out_w'], prezeroed=False)
         _, dctx2 = K.linear_dx(ds2b, W.s('ca_out_w'), B, D, D, want_bf16=True)
-        dq2 = torch.empty((B, D), dtype=BF16, device=dev)
-        dkv2 = torch.empty((Mv, 2 * D), dtype=BF16, device=dev)
+        dq2 = torch.empty((B, D), dtype=K.HALF(), device=dev)
+        dkv2 = torch.empty((Mv, 2 * D), dtype=K.HALF(), device=dev)
         kv2 = S['kv2']
         K.attention_bwd(S['q2'], kv2[:, :D], kv2[:, D:], dctx2, D, 2 * D, 2 * D, B, H, 1, Skv, Dh, dq2, dkv2[:, :D], dkv2[:, D:],
                         D, 2 * D, 2 * D, S['km'], Drop(pd, seed, 3),
@@ -423,8 +423,8 @@ class CrossModalAttentionRunner:
         K.linear_dw(ds1b, S['ctx'], B, D, D, out=G['sa_out_w'], prezeroed=False)
         _, dctx = K.linear_dx(ds1b, W.s('sa_out_w'), B, D, D, want_bf16=True)
         kvs = S['kvs']
-        dq0 = torch.empty((B, D), dtype=BF16, device=dev)
-        dkvs = torch.empty((M, 2 * D), dtype=BF16, device=dev)
+        dq0 = torch.empty((B, D), dtype=K.HALF(), device=dev)
+        dkvs = torch.empty((M, 2 * D), dtype=K.HALF(), device=dev)
         K.attention_bwd(S['q0'], kvs[:, :D], kvs[:, D:], dctx, D, 2 * D, 2 * D, B, H, 1, Sq, Dh, dq0, dkvs[:, :D], dkvs[:, D:],
                         D, 2 * D, 2 * D, S['qm'], Drop(pd, seed, 1),
                         dq_colsum=G['sa_in_b'][:D], dk_colsum=G['sa_in_b'][D:2 * D], dv_colsum=G['sa_in_b'][2 * D:])

@@ -12,7 +12,12 @@ import torch
 from . import lib as _l
 
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32
+
+
+def HALF():
+    """torch dtype of the active library's 16-bit operand type (hip.lib.set_half): bfloat16 by default, float16 in fp16 mode."""
+    return torch.float16 if _l.half() == 'fp16' else torch.bfloat16
 
 
 class HipError(RuntimeError):
@@ -50,10 +55,6 @@ class Drop:
 
 NO_DROP = Drop()
 
-# bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream: (flop, start, end)
-GEMM_PROFILE = None
-PROFILE_TAG = ''        # bench.py: region label attached to each GEMM_PROFILE entry ('fusion' inside the cross-attention fusion block)
-
 
 def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=None, pre_bf16=None, bias=None,
          residual=None, act_grad_of=None, act=ACT_NONE, act_bwd=ACT_NONE, drop: Drop = NO_DROP, allow_split_k=False,
@@ -71,13 +72,6 @@ def gemm(a, b, M, N, K, lda, ldb, a_kc=True, b_kc=True, out_f32=None, out_bf16=N
     d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
     d.split_k, d.allow_split_k, d.tile_hint = split_k, int(allow_split_k), tile_hint
     d.colsum, d.c_prezeroed = _p(colsum), int(c_prezeroed)
-    if GEMM_PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
-        e1.record()
-        GEMM_PROFILE.append((2.0 * M * N * K, e0, e1, PROFILE_TAG))
-        return
     _chk(L().vqa_gemm_bf16(C.byref(d), _stream()), f'vqa_gemm_bf16(M={M},N={N},K={K})')
 
 
@@ -88,8 +82,8 @@ def linear_fwd(x_bf16, w_bf16, bias, M, N, K, *, want_f32=False, want_bf16=False
     """y = drop(act(x W^T + b)) + residual.  Returns (y_f32|None, y_bf16|None, pre_bf16|None)."""
     dev = x_bf16.device
     yf = torch.empty((M, N), dtype=F32, device=dev) if want_f32 else None
-    yb = torch.empty((M, N), dtype=BF16, device=dev) if want_bf16 else None
-    pre = torch.empty((M, N), dtype=BF16, device=dev) if want_pre else None
+    yb = torch.empty((M, N), dtype=HALF(), device=dev) if want_bf16 else None
+    pre = torch.empty((M, N), dtype=HALF(), device=dev) if want_pre else None
     gemm(x_bf16, w_bf16, M, N, K, lda or K, K, True, True, out_f32=yf, out_bf16=yb, pre_bf16=pre, bias=bias,
          residual=residual, act=act, drop=drop)
     return yf, yb, pre
@@ -101,7 +95,7 @@ def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, resi
     column sums of dx before the residual: the bias gradient of the Linear that produced the activation input."""
     dev = dy_bf16.device
     of = torch.empty((M, K), dtype=F32, device=dev) if want_f32 else None
-    ob = torch.empty((M, K), dtype=BF16, device=dev) if want_bf16 else None
+    ob = torch.empty((M, K), dtype=HALF(), device=dev) if want_bf16 else None
     gemm(dy_bf16, w_bf16, M, K, N, ldy or N, ldw or K, True, False, out_f32=of, out_bf16=ob, residual=residual,
          act_grad_of=act_grad_of, act_bwd=act_bwd, drop=drop, colsum=colsum)
     return of, ob
@@ -139,13 +133,7 @@ def _launch_group(pending):
             # dW[N,K] = dy[M,N]^T x[M,K]: GEMM rows = N, columns = K, reduction over the M tokens
             it.a, it.b, it.c_f32 = _p(dy), _p(x), _p(out)
             it.M, it.N, it.K, it.lda, it.ldb, it.ldc = N, Kd, M, ldy, ldx, out.stride(0)
-        if GEMM_PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         _chk(L().vqa_gemm_bf16_grouped(_group_items, len(chunk), 0, 0, _stream()), 'vqa_gemm_bf16_grouped')
-        if GEMM_PROFILE is not None:
-            e1.record()
-            GEMM_PROFILE.append((sum(2.0 * a[2] * a[3] * a[4] for a in chunk), e0, e1, 'wgrad'))
 
 
 def wgrad_flush():
@@ -216,7 +204,7 @@ def colsum_f32(x, M, N, ld=None, out=None):
 def cast_bf16(x_f32, out=None):
     x_f32 = x_f32.contiguous()
     if out is None:
-        out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+        out = torch.empty(x_f32.shape, dtype=HALF(), device=x_f32.device)
     _chk(L().vqa_cast_f32_bf16(_p(x_f32), _p(out), x_f32.numel(), _stream()), 'vqa_cast_f32_bf16')
     return out
 
@@ -233,14 +221,14 @@ def cast_multi(jobs_dev, njobs, max_n):
 
 def add_f32(a, b, want_f32=True, want_bf16=False):
     y = torch.empty_like(a) if want_f32 else None
-    yb = torch.empty(a.shape, dtype=BF16, device=a.device) if want_bf16 else None
+    yb = torch.empty(a.shape, dtype=HALF(), device=a.device) if want_bf16 else None
     _chk(L().vqa_add_f32(_p(a), _p(b), _p(y), _p(yb), a.numel(), _stream()), 'vqa_add_f32')
     return y, yb
 
 
 def gather_rows(src, idx_i32, n, D, ld_src=None, want_f32=False, want_bf16=True):
     dst = torch.empty((n, D), dtype=F32, device=src.device) if want_f32 else None
-    dstb = torch.empty((n, D), dtype=BF16, device=src.device) if want_bf16 else None
+    dstb = torch.empty((n, D), dtype=HALF(), device=src.device) if want_bf16 else None
     _chk(L().vqa_gather_rows_f32(_p(src), _p(idx_i32), _p(dst), _p(dstb), n, D, ld_src or D, _stream()), 'vqa_gather_rows_f32')
     return dst, dstb
 
@@ -250,7 +238,7 @@ def gather_rows(src, idx_i32, n, D, ld_src=None, want_f32=False, want_bf16=True)
 def layernorm_fwd(x, gamma, beta, rows, cols, *, add=None, want_f32=True, want_bf16=False, eps=1e-5, drop: Drop = NO_DROP):
     dev = x.device
     y = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
-    yb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
+    yb = torch.empty((rows, cols), dtype=HALF(), device=dev) if want_bf16 else None
     mean = torch.empty((rows,), dtype=F32, device=dev)
     rstd = torch.empty((rows,), dtype=F32, device=dev)
     _chk(L().vqa_layernorm_fwd(_p(x), _p(add), _p(gamma), _p(beta), _p(y), _p(yb), _p(mean), _p(rstd), rows, cols, eps,
@@ -285,7 +273,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=T
     ADDED to with fp32 atomics: one launch, no workspace (see include/vqa_hip.h)."""
     dev = dy.device
     dx = torch.empty((rows, cols), dtype=F32, device=dev) if want_f32 else None
-    dxb = torch.empty((rows, cols), dtype=BF16, device=dev) if want_bf16 else None
+    dxb = torch.empty((rows, cols), dtype=HALF(), device=dev) if want_bf16 else None
     ws = None
     if LN_REDUCE_GROUPED and defer and dgamma is not None and dbeta is not None:
         # partial sums only; ln_reduce_flush() (end of the block's backward) sums the partials of all deferred calls in one launch
@@ -318,7 +306,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=T
 
 def attention_fwd(q, k, v, ldq, ldk, ldv, B, H, Sq, Skv, Dh, mask_u8=None, drop: Drop = NO_DROP, out=None):
     if out is None:
-        out = torch.empty((B * Sq, H * Dh), dtype=BF16, device=q.device)
+        out = torch.empty((B * Sq, H * Dh), dtype=HALF(), device=q.device)
     d = _ad
     d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), _p(out)
     d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, H * Dh
@@ -353,7 +341,7 @@ def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, ld
 
 def patchify(pixels, ps):
     B, Cc, H, W = pixels.shape
-    out = torch.empty((B * (H // ps) * (W // ps), Cc * ps * ps), dtype=BF16, device=pixels.device)
+    out = torch.empty((B * (H // ps) * (W // ps), Cc * ps * ps), dtype=HALF(), device=pixels.device)
     _chk(L().vqa_patchify_bf16(_p(pixels), _p(out), B, Cc, H, W, ps, _stream()), 'vqa_patchify_bf16')
     return out
 
@@ -365,22 +353,47 @@ def clip_assemble(E, cls, pos, B, P, D):
 
 
 def clip_assemble_bwd(du, B, P, D, dcls, dpos):
-    dE = torch.empty((B * P, D), dtype=BF16, device=du.device)
+    dE = torch.empty((B * P, D), dtype=HALF(), device=du.device)
     _chk(L().vqa_clip_assemble_bwd(_p(du), _p(dE), _p(dcls), _p(dpos), B, P, D, _stream()), 'vqa_clip_assemble_bwd')
     return dE
+
+
+_status = {}
+
+
+def status_word(device):
+    """Per-device int32 word the index-consuming kernels clear when they meet an out-of-range token id / position id / label
+    (they never dereference it; torch would device-assert).  ``check_device_status`` reads it (one host sync)."""
+    dev = torch.device(device)
+    w = _status.get(dev)
+    if w is None:
+        w = _status[dev] = torch.ones(1, dtype=torch.int32, device=dev)
+    return w
+
+
+def check_device_status(device=None):
+    """Raises IndexError if any kernel since the last check saw an out-of-range id / label (host sync: call it where the
+    reference's loop already syncs, e.g. next to ``loss.item()``); resets the word."""
+    for dev, w in _status.items():
+        if device is not None and torch.device(device) != dev:
+            continue
+        if int(w.item()) != 1:
+            w.fill_(1)
+            raise IndexError('HIP path: a token id, position id or label was out of range (ids must be in [0, vocab), '
+                             'labels in [0, num_answers) or -100)')
 
 
 def roberta_embed_fwd(ids, word, pos, type0, B, S, D, pad_id=1):
     pos_ids = torch.empty((B, S), dtype=torch.int32, device=ids.device)
     u = torch.empty((B * S, D), dtype=F32, device=ids.device)
-    _chk(L().vqa_roberta_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(pos_ids), _p(u), B, S, D, pad_id, _stream()),
-         'vqa_roberta_embed_fwd')
+    _chk(L().vqa_roberta_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(pos_ids), _p(u), B, S, D, pad_id, word.shape[0], pos.shape[0],
+                                   _p(status_word(ids.device)), _stream()), 'vqa_roberta_embed_fwd')
     return u, pos_ids
 
 
 def roberta_embed_bwd(du, ids, pos_ids, dword, dpos, dtype0, B, S, D, pad_id=1):
-    _chk(L().vqa_roberta_embed_bwd(_p(du), _p(ids), _p(pos_ids), _p(dword), _p(dpos), _p(dtype0), B, S, D, pad_id, _stream()),
-         'vqa_roberta_embed_bwd')
+    _chk(L().vqa_roberta_embed_bwd(_p(du), _p(ids), _p(pos_ids), _p(dword), _p(dpos), _p(dtype0), B, S, D, pad_id, dword.shape[0], dpos.shape[0],
+                                   _stream()), 'vqa_roberta_embed_bwd')
 
 
 # ---- loss ------------------------------------------------------------------------------------------------------------
@@ -388,19 +401,19 @@ def roberta_embed_bwd(du, ids, pos_ids, dword, dpos, dtype0, B, S, D, pad_id=1):
 def ce_argmax_fwd(logits, labels, B, Cn):
     dev = logits.device
     row_loss = torch.empty((B,), dtype=F32, device=dev)
-    loss = torch.empty((), dtype=F32, device=dev)
+    loss2 = torch.empty((2,), dtype=F32, device=dev)          # {mean over the non-ignored rows, their count}
     pred = torch.empty((B,), dtype=torch.int64, device=dev)
     lse = torch.empty((B,), dtype=F32, device=dev)
-    _chk(L().vqa_softmax_ce_argmax_fwd(_p(logits), Cn, _p(labels), _p(row_loss), _p(loss) if labels is not None else None,
-                                       _p(pred), _p(lse), B, Cn, _stream()), 'vqa_softmax_ce_argmax_fwd')
-    return (loss if labels is not None else None), pred, lse
+    _chk(L().vqa_softmax_ce_argmax_fwd(_p(logits), Cn, _p(labels), _p(row_loss), _p(loss2) if labels is not None else None,
+                                       _p(pred), _p(lse), B, Cn, _p(status_word(dev)), _stream()), 'vqa_softmax_ce_argmax_fwd')
+    return (loss2[0] if labels is not None else None), pred, lse, (loss2[1:] if labels is not None else None)
 
 
-def ce_bwd(logits, labels, lse, dloss, B, Cn, want_f32=True, want_bf16=False):
+def ce_bwd(logits, labels, lse, dloss, B, Cn, nvalid=None, want_f32=True, want_bf16=False):
     dev = logits.device
     dl = torch.empty((B, Cn), dtype=F32, device=dev) if want_f32 else None
-    dlb = torch.empty((B, Cn), dtype=BF16, device=dev) if want_bf16 else None
-    _chk(L().vqa_softmax_ce_bwd(_p(logits), Cn, _p(labels), _p(lse), _p(dloss), _p(dl), _p(dlb), B, Cn, _stream()),
+    dlb = torch.empty((B, Cn), dtype=HALF(), device=dev) if want_bf16 else None
+    _chk(L().vqa_softmax_ce_bwd(_p(logits), Cn, _p(labels), _p(lse), _p(dloss), _p(nvalid), _p(dl), _p(dlb), B, Cn, _stream()),
          'vqa_softmax_ce_bwd')
     return dl, dlb
 
@@ -409,7 +422,7 @@ def ce_bwd(logits, labels, lse, dloss, B, Cn, want_f32=True, want_bf16=False):
 
 def dropout_f32(x, drop: Drop, want_f32=True, want_bf16=False):
     y = torch.empty_like(x) if want_f32 else None
-    yb = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
+    yb = torch.empty(x.shape, dtype=HALF(), device=x.device) if want_bf16 else None
     _chk(L().vqa_dropout_f32(_p(x), _p(y), _p(yb), x.numel(), drop.p, drop.seed, drop.stream, _stream()), 'vqa_dropout_f32')
     return y, yb
 

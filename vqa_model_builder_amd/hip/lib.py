@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libvqa_hip.so')
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libvqa_hip.so')              # bfloat16 operands
+LIB_PATH_F16 = os.path.join(os.path.dirname(_HERE), 'csrc', 'libvqa_hip_f16.so')      # IEEE fp16 operands (same sources, -DVQA_HALF_F16)
 
 vp, i32, f32, u64, u32, sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
 
@@ -45,7 +46,10 @@ class VqaAdamWDesc(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/vqa_hip.h declares (tests check this)
 SIGNATURES = {
     'vqa_abi_version': (i32, []),
+    'vqa_half_kind': (i32, []),
     'vqa_gemm_bf16': (i32, [C.POINTER(VqaGemmDesc), vp]),
+    'vqa_gemm_profile': (None, [i32, i32]),
+    'vqa_gemm_profile_collect': (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'vqa_set_gemm_use_tr': (None, [i32]),
     'vqa_set_gemm_pipeline': (None, [i32]),
     'vqa_set_gemm_group_m': (None, [i32]),
@@ -66,10 +70,10 @@ SIGNATURES = {
     'vqa_set_attention_mfma': (None, [i32]),
     'vqa_attention_fwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
     'vqa_attention_bwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
-    'vqa_roberta_embed_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    'vqa_roberta_embed_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    'vqa_softmax_ce_argmax_fwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
-    'vqa_softmax_ce_bwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_roberta_embed_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'vqa_roberta_embed_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'vqa_softmax_ce_argmax_fwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'vqa_softmax_ce_bwd': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     'vqa_router_gate_fwd': (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_router_gate_bwd': (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_router_topk_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -94,27 +98,51 @@ SIGNATURES = {
     'vqa_attention_bwd_ws_floats': (u64, [i32, i32, i32, i32, i32]),
     'vqa_opt_chunk_elems': (i32, []),
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
-    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, f32, vp]),
+    'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
+    'vqa_amp_update': (i32, [vp, vp, f32, f32, i32, vp]),
+    'vqa_opt_advance': (i32, [vp, vp, vp]),
     'vqa_adamw_step': (i32, [C.POINTER(VqaAdamWDesc), vp]),
     'vqa_sumsq_f32': (i32, [vp, u64, vp, vp]),
 }
 
 _lib = None
+_libs = {}            # half kind -> typed handle
+_half = 'bf16'        # operand type of the ACTIVE library: 'bf16' (default) | 'fp16'
 
 
 class HipLibraryMissing(RuntimeError):
     pass
 
 
+def half() -> str:
+    return _half
+
+
+def set_half(kind: str):
+    """Selects which build of the kernels every later launch uses: 'bf16' (torch autocast's bf16 scheme) or 'fp16' (what the
+    reference's main loop runs under: autocast fp16 + GradScaler, training_pipeline.py:346-347,457).  Process-wide; switch
+    BEFORE building / moving a model (weight shadows and saved activations are of the active type)."""
+    global _half, _lib
+    if kind not in ('bf16', 'fp16'):
+        raise ValueError(f"compute dtype must be 'bf16' or 'fp16' (got {kind!r})")
+    if kind != _half:
+        _half, _lib = kind, None
+    return load()
+
+
 def load(path: str = None):
-    """Loads the shared library and types every entry point.  Raises HipLibraryMissing if it is not built."""
+    """Loads the shared library of the active operand type and types every entry point.  Raises HipLibraryMissing if it
+    is not built."""
     global _lib
     if _lib is not None and path is None:
+        return _lib
+    if path is None and _half in _libs:
+        _lib = _libs[_half]
         return _lib
     # torch ships its own libamdhip64: it must be in the process BEFORE this library is dlopen-ed, so that both bind to
     # the same HIP runtime (otherwise torch's streams / allocations are foreign to our launches: hipErrorNoDevice)
     import torch  # noqa: F401
-    p = path or LIB_PATH
+    p = path or (LIB_PATH_F16 if _half == 'fp16' else LIB_PATH)
     if not os.path.exists(p):
         raise HipLibraryMissing(
             f'{p} not found: build it with `python -m vqa_model_builder_amd.csrc.build` '
@@ -124,5 +152,7 @@ def load(path: str = None):
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype, fn.argtypes = res, args
     if path is None:
-        _lib = lib
+        if lib.vqa_half_kind() != (1 if _half == 'fp16' else 0):
+            raise HipLibraryMissing(f'{p} was built for the other operand type: rebuild (python -m vqa_model_builder_amd.csrc.build --force)')
+        _lib = _libs[_half] = lib
     return lib

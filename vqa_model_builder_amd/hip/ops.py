@@ -11,7 +11,7 @@ from . import kernels as K
 from .kernels import ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, Drop, NO_DROP  # noqa: F401
 from .blocks import new_seed
 
-F32, BF16 = torch.float32, torch.bfloat16
+F32 = torch.float32
 
 # ---- weight shadows for stand-alone parameters (version-checked bf16 copies) --------------------------------------
 _shadow_cache = {}
@@ -27,7 +27,7 @@ def bump_shadow_generation():
 def shadow_of(param: torch.Tensor) -> torch.Tensor:
     key = id(param)
     ent = _shadow_cache.get(key)
-    sig = (param.data_ptr(), param._version, param.device, _shadow_generation)
+    sig = (param.data_ptr(), param._version, param.device, _shadow_generation, K.HALF())
     if ent is None or ent[0] != sig or ent[2]() is not param:
         import weakref
         sh = K.cast_bf16(param.detach())
@@ -40,7 +40,7 @@ def standalone_shadow(param: torch.Tensor):
     """The cached bf16 copy of a stand-alone parameter if one exists for its current storage (a fused optimiser writes it in
     the same pass as the parameter instead of leaving a cast launch to the next forward), else None."""
     ent = _shadow_cache.get(id(param))
-    if ent is None or ent[2]() is not param or ent[0][0] != param.data_ptr() or ent[0][2] != param.device:
+    if ent is None or ent[2]() is not param or ent[0][0] != param.data_ptr() or ent[0][2] != param.device or ent[1].dtype != K.HALF():
         return None
     return ent[1]
 
@@ -49,11 +49,11 @@ def mark_shadow_fresh(param: torch.Tensor):
     """The optimiser has just written ``standalone_shadow(param)``: the next ``shadow_of`` must not re-cast it."""
     ent = _shadow_cache.get(id(param))
     if ent is not None:
-        _shadow_cache[id(param)] = ((param.data_ptr(), param._version, param.device, _shadow_generation), ent[1], ent[2])
+        _shadow_cache[id(param)] = ((param.data_ptr(), param._version, param.device, _shadow_generation, ent[1].dtype), ent[1], ent[2])
 
 
 def _as_bf16(x):
-    return x if x.dtype == BF16 else K.cast_bf16(x.float() if x.dtype != F32 else x)
+    return x if x.dtype == K.HALF() else K.cast_bf16(x.float() if x.dtype != F32 else x)
 
 
 def _need_cuda(x, what):
@@ -113,7 +113,7 @@ class _LinearFn(torch.autograd.Function):
             dyp[:, :N] = dy
             dy = dyp
         if pre is not None or drop.p > 0:
-            dyb = torch.empty((M, Np), dtype=BF16, device=dy.device)
+            dyb = torch.empty((M, Np), dtype=K.HALF(), device=dy.device)
             K._chk(K.L().vqa_act_drop_bwd(dy.data_ptr(), K._p(pre), act, None, dyb.data_ptr(), dy.numel(), drop.p, drop.seed,
                                           drop.stream, K._stream()), 'vqa_act_drop_bwd')
         else:
@@ -185,9 +185,9 @@ class _AttentionFn(torch.autograd.Function):
         qb, kb, vb, mask_u8 = ctx.saved_tensors
         B, Sq, Skv, D, H, drop = ctx.meta
         dob = _as_bf16(do.reshape(-1, D).contiguous())
-        dq = torch.empty((B * Sq, D), dtype=BF16, device=do.device)
-        dk = torch.empty((B * Skv, D), dtype=BF16, device=do.device)
-        dv = torch.empty((B * Skv, D), dtype=BF16, device=do.device)
+        dq = torch.empty((B * Sq, D), dtype=K.HALF(), device=do.device)
+        dk = torch.empty((B * Skv, D), dtype=K.HALF(), device=do.device)
+        dv = torch.empty((B * Skv, D), dtype=K.HALF(), device=do.device)
         K.attention_bwd(qb, kb, vb, dob, D, D, D, B, H, Sq, Skv, D // H, dq, dk, dv, D, D, D, mask_u8, drop)
         return K.cast_f32(dq).view(B, Sq, D), K.cast_f32(dk).view(B, Skv, D), K.cast_f32(dv).view(B, Skv, D), None, None, None
 
@@ -242,29 +242,38 @@ class _CEFn(torch.autograd.Function):
     def forward(ctx, logits, labels):
         B, Cn = logits.shape
         lg = logits.contiguous().float()
-        loss, pred, lse = K.ce_argmax_fwd(lg, labels.contiguous(), B, Cn)
-        ctx.save_for_backward(lg, labels, lse)
+        loss, pred, lse, nvalid = K.ce_argmax_fwd(lg, labels, B, Cn)
+        ctx.save_for_backward(lg, labels, lse, nvalid)
         ctx.mark_non_differentiable(pred)
         return loss, pred
 
     @staticmethod
     def backward(ctx, dloss, _dpred):
-        lg, labels, lse = ctx.saved_tensors
+        lg, labels, lse, nvalid = ctx.saved_tensors
         B, Cn = lg.shape
-        dl, _ = K.ce_bwd(lg, labels, lse, dloss.contiguous().float(), B, Cn)
+        dl, _ = K.ce_bwd(lg, labels, lse, dloss.contiguous().float(), B, Cn, nvalid=nvalid)
         return dl, None
 
 
 def cross_entropy_argmax(logits, labels):
-    """(mean CE loss, argmax ids) in one pass over the logits (reference vqa_model.py:711-716)."""
+    """(mean CE loss, argmax ids) in one pass over the logits (reference vqa_model.py:711-716: ``F.cross_entropy`` defaults,
+    i.e. ``ignore_index=-100`` rows are skipped and not counted by the mean).  Labels are validated on the host for what costs no
+    sync (rank, device, integer dtype -- int32 from a collator is widened, a float tensor is an error as in torch); their RANGE is
+    checked on the device: an out-of-range label is never dereferenced, poisons the loss with NaN and clears the status word
+    that ``kernels.check_device_status`` reads."""
     _need_cuda(logits, 'cross_entropy_argmax')
-    return _CEFn.apply(logits, labels)
+    if labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+        raise ValueError(f'cross_entropy_argmax: labels must be [batch] class indices (got {tuple(labels.shape)} for logits {tuple(logits.shape)})')
+    if labels.device != logits.device:
+        raise RuntimeError(f'cross_entropy_argmax: labels on {labels.device}, logits on {logits.device}')
+    if labels.dtype.is_floating_point or labels.dtype == torch.bool:
+        raise RuntimeError(f'cross_entropy_argmax: labels must be an integer tensor of class indices (got {labels.dtype})')
+    return _CEFn.apply(logits, labels.long().contiguous())
 
 
 def argmax(logits):
     B, Cn = logits.shape
-    _, pred, _ = K.ce_argmax_fwd(logits.detach().contiguous().float(), None, B, Cn)
-    return pred
+    return K.ce_argmax_fwd(logits.detach().contiguous().float(), None, B, Cn)[1]
 
 
 class _AddFn(torch.autograd.Function):
@@ -294,7 +303,7 @@ class _BilinearFn(torch.autograd.Function):
         B, D1 = x1.shape
         D2, Do = x2.shape[1], weight.shape[0]
         x1c, x2c = x1.contiguous().float(), x2.contiguous().float()
-        z = torch.empty((B, D1 * D2), dtype=BF16, device=x1.device)
+        z = torch.empty((B, D1 * D2), dtype=K.HALF(), device=x1.device)
         K._chk(K.L().vqa_outer_bf16(x1c.data_ptr(), x2c.data_ptr(), z.data_ptr(), B, D1, D2, K._stream()), 'vqa_outer_bf16')
         w = shadow_of(weight).view(Do, D1 * D2)
         y = torch.zeros((B, Do), dtype=F32, device=x1.device)

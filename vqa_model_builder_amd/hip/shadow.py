@@ -49,7 +49,7 @@ class ShadowSet:
 
     # -- run time ------------------------------------------------------------------------------------------------
     def _materialise(self, device):
-        self._arena = {'bf16': torch.empty(max(self._size['bf16'], 8), dtype=torch.bfloat16, device=device),
+        self._arena = {'bf16': torch.empty(max(self._size['bf16'], 8), dtype=K.HALF(), device=device),
                        'f32': torch.empty(max(self._size['f32'], 8), dtype=torch.float32, device=device)}
         rows = []
         for _, p, arena, off, n in self._plan:
@@ -62,7 +62,8 @@ class ShadowSet:
     def refresh(self, device):
         """Re-casts if any source parameter changed (version counter or storage)."""
         ptr_sig = tuple(p.data_ptr() for _, p, _, _, _ in self._plan)
-        if self._jobs is None or ptr_sig != getattr(self, '_ptr_sig', None) or self._arena['bf16'].device != device:
+        if (self._jobs is None or ptr_sig != getattr(self, '_ptr_sig', None) or self._arena['bf16'].device != device
+                or self._arena['bf16'].dtype != K.HALF()):        # operand type switched (hip.lib.set_half): new arena, new casts
             for _, p, _, _, _ in self._plan:
                 if p.device != device:
                     raise RuntimeError(f'parameter on {p.device}, expected {device}: move the module to the GPU first')

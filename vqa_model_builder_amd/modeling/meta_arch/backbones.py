@@ -300,7 +300,17 @@ class RobertaBackbone(nn.Module):
 
     def forward(self, input_ids, attention_mask=None):
         _require_cuda(input_ids, 'RobertaBackbone')
+        c = self.config
+        if input_ids.dim() != 2 or input_ids.dtype.is_floating_point or input_ids.dtype == torch.bool:
+            raise ValueError(f'RobertaBackbone: input_ids must be an integer [batch, seq] tensor (got {input_ids.dtype} {tuple(input_ids.shape)})')
+        if input_ids.shape[1] + c.pad_token_id + 1 > c.max_position_embeddings:      # position ids run up to seq + pad_id (HF raises an IndexError here)
+            raise ValueError(f'RobertaBackbone: sequence length {input_ids.shape[1]} needs position ids up to {input_ids.shape[1] + c.pad_token_id}, '
+                             f'max_position_embeddings is {c.max_position_embeddings}')
+        input_ids = input_ids.long()                           # int32 ids from a collator are widened, never reinterpreted
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
+        if attention_mask.shape != input_ids.shape or attention_mask.device != input_ids.device:
+            raise ValueError(f'RobertaBackbone: attention_mask {tuple(attention_mask.shape)} on {attention_mask.device} does not match '
+                             f'input_ids {tuple(input_ids.shape)} on {input_ids.device}')
         out = _BlockFn.apply(self, 2, input_ids, attention_mask, *[p for _, p in self._flat])
         return SimpleNamespace(last_hidden_state=out)

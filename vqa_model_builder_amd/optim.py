@@ -18,15 +18,25 @@ from .hip import ops as _ops
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=None):
+    def __init__(self, params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=None, loss_scale=None,
+                 growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        """``loss_scale`` (fp16 operand mode; None = off): a float = static scale, ``'dynamic'`` = torch.amp.GradScaler's
+        policy (start 65536, x ``backoff_factor`` after a step with non-finite gradients -- which is skipped --, x
+        ``growth_factor`` after ``growth_interval`` clean steps), kept in device memory and applied inside the update kernels:
+        ``scale_loss(loss).backward()`` then ``step()`` replaces the reference loop's scaler.scale / unscale_ / step / update
+        sequence (training_pipeline.py:466-502) without a host read of found_inf.  A caller that drives its own
+        ``GradScaler`` needs none of this: the gradients are ordinary fp32 tensors."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
+        self._amp_cfg = None
+        if loss_scale is not None:
+            dynamic = loss_scale == 'dynamic'
+            self._amp_cfg = (65536.0 if dynamic else float(loss_scale), dynamic, float(growth_factor), float(backoff_factor), int(growth_interval))
+        self._amp = None                                  # device floats {scale, growth_tracker, found_inf of the last step}
         self._shadow_sets = []
         self._tables = {}
         self._norm2 = None
         self._hyper = None                                # HIP-graph mode: per group device floats {lr, step}
-        self._hyper_inc = None
-        self._pending_replays = 0
         self._staging = {}                                # HIP-graph mode: pinned host rows per job table
         self.grad_prescale = 1.0                          # DP: gradients hold the all-reduced SUM; 1/world is applied here
 
@@ -46,9 +56,28 @@ class FusedAdamW(torch.optim.Optimizer):
             if len(steps) > 1:
                 raise RuntimeError('FusedAdamW.make_capturable: parameters of one group have different step counts')
             self._hyper.append(torch.tensor([float(group['lr']), float(steps.pop() if steps else 0)], dtype=torch.float32).to(device))
-        self._hyper_inc = torch.tensor([0.0, 1.0], dtype=torch.float32).to(device)
         self._staging = {slot: torch.empty(tuple(c[1].shape), dtype=torch.int64).pin_memory() for slot, c in self._tables.items()}
         return self
+
+    # ---- loss scaling (fp16 operand mode) -----------------------------------------------------------------------------
+    def _amp_state(self, device):
+        if self._amp is None or self._amp.device != torch.device(device):
+            self._amp = torch.tensor([self._amp_cfg[0], 0.0, 0.0, 0.0], dtype=torch.float32).to(device)
+        return self._amp
+
+    def scale_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        """loss x the current scale (a device multiply: replays of a captured step follow the scale)."""
+        if self._amp_cfg is None:
+            return loss
+        return loss * self._amp_state(loss.device)[0]
+
+    @property
+    def loss_scale(self):
+        return None if self._amp_cfg is None else (float(self._amp[0]) if self._amp is not None else self._amp_cfg[0])
+
+    def found_inf(self) -> bool:
+        """Whether the last step was skipped for non-finite gradients (host read: diagnostics / tests only)."""
+        return self._amp is not None and float(self._amp[2]) != 0.0
 
     def refresh_lr(self):
         """Copies the groups' current ``lr`` to the device words (call between replays when a scheduler changed it)."""
@@ -57,16 +86,20 @@ class FusedAdamW(torch.optim.Optimizer):
                 h[0:1].fill_(float(group['lr']))
 
     def note_replays(self, n=1):
-        """A captured step was replayed ``n`` times: the python-side ``state[p]['step']`` counters catch up lazily."""
-        self._pending_replays += n
+        """Kept for callers of round 1: the step count of a capturable optimiser lives on the device (``hyper[1]``) and the
+        python-side ``state[p]['step']`` is read back from it on demand (``sync_step_counts``), so nothing to note."""
 
     def sync_step_counts(self):
-        if self._pending_replays:
-            for group in self.param_groups:
-                for p in group['params']:
-                    if p in self.state and self.state[p]:
-                        self.state[p]['step'] = int(self.state[p]['step']) + self._pending_replays
-            self._pending_replays = 0
+        """Capturable mode: ``state[p]['step']`` := the device step count of the parameter's group -- the number of updates
+        actually APPLIED (the capture pass applies none; a step skipped for non-finite fp16 gradients does not count).  One
+        host read per group; called by ``state_dict()``."""
+        if self._hyper is None:
+            return
+        for group, h in zip(self.param_groups, self._hyper):
+            n = int(round(float(h[1])))
+            for p in group['params']:
+                if p in self.state and self.state[p]:
+                    self.state[p]['step'] = n
 
     def state_dict(self):
         self.sync_step_counts()
@@ -85,8 +118,12 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        self.sync_step_counts()
         lib, st = K.L(), K._stream()
+        if self._amp_cfg is not None and self._hyper is None:
+            # a step skipped for non-finite gradients must not advance the bias corrections: count on the device from the start
+            first = next((p for g in self.param_groups for p in g['params'] if p.grad is not None), None)
+            if first is not None:
+                self.make_capturable(first.device)
         shadows = self._shadow_map()
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
         standalone = []
@@ -102,7 +139,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     state['step'] = 0
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state['step'] = int(state['step']) + 1
+                if self._hyper is None:                     # capturable mode counts on the device (bias corrections come from there)
+                    state['step'] = int(state['step']) + 1
                 sp, sk = shadows.get(id(p), (0, 0))
                 if sp == 0:                                 # stand-alone parameter (tail ops, experts): its cached bf16 copy, if any
                     sh = _ops.standalone_shadow(p)
@@ -144,7 +182,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._hyper is not None and len(tables) != len({t[5] for t in tables}):
             raise RuntimeError('FusedAdamW (capturable): parameters of one group have different step counts')
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
-        if clip:
+        amp = None
+        if self._amp_cfg is not None:
+            amp = self._amp_state(dev)
+        if clip or amp is not None:
             self._norm2.zero_()
             for _, _, tab, chunks, nch, _ in tables:
                 K._chk(lib.vqa_sumsq_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr(), st), 'vqa_sumsq_multi')
@@ -153,12 +194,19 @@ class FusedAdamW(torch.optim.Optimizer):
             hyper = None
             if self._hyper is not None:
                 hyper = self._hyper[gi]
-                hyper.add_(self._hyper_inc)               # device-side step += 1 (captured with the step)
-            K._chk(lib.vqa_adamw_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr() if clip else None,
-                                       float(self.max_grad_norm or 0.0), float(group['lr']), b1, b2, group['eps'],
-                                       1.0 - b1 ** step, 1.0 - b2 ** step, hyper.data_ptr() if hyper is not None else None,
-                                       float(self.grad_prescale), st),
+                # device-side step += 1 (captured with the step) unless this step's gradients are non-finite
+                K._chk(lib.vqa_opt_advance(hyper.data_ptr(), self._norm2.data_ptr() if amp is not None else None, st), 'vqa_opt_advance')
+            K._chk(lib.vqa_adamw_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr() if (clip or amp is not None) else None,
+                                       float(self.max_grad_norm or 0.0) if clip else 0.0, float(group['lr']), b1, b2, group['eps'],
+                                       1.0 - b1 ** max(step, 1), 1.0 - b2 ** max(step, 1), hyper.data_ptr() if hyper is not None else None,
+                                       float(self.grad_prescale), amp.data_ptr() if amp is not None else None, st),
                    'vqa_adamw_multi')
+        if amp is not None:
+            _, dynamic, growth, backoff, interval = self._amp_cfg
+            if dynamic:
+                K._chk(lib.vqa_amp_update(amp.data_ptr(), self._norm2.data_ptr(), growth, backoff, interval, st), 'vqa_amp_update')
+            else:                                           # static scale: only record found_inf
+                K._chk(lib.vqa_amp_update(amp.data_ptr(), self._norm2.data_ptr(), 1.0, 1.0, 1 << 30, st), 'vqa_amp_update')
         _ops.bump_shadow_generation()                      # stand-alone bf16 shadows this step did not write are stale now
         for p in standalone:
             _ops.mark_shadow_fresh(p)
@@ -166,4 +214,6 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def grad_norm(self):
         """Global gradient norm of the last clipped step (device scalar)."""
-        return None if self._norm2 is None else self._norm2.sqrt() * self.grad_prescale
+        if self._norm2 is None:
+            return None
+        return self._norm2.sqrt() * self.grad_prescale / (self._amp[0] if self._amp is not None else 1.0)
