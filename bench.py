@@ -238,10 +238,10 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
             def hook(*_a):
                 L.vqa_gemm_profile(1, v)
             return hook
+        n_prof = 3
+        eager_step()                                  # settle allocator / shadows outside the graph (not recorded)
         hooks = [model.fusion.register_forward_pre_hook(_tag(1)), model.fusion.register_forward_hook(_tag(0)),
                  model.fusion.register_full_backward_pre_hook(_tag(1)), model.fusion.register_full_backward_hook(_tag(0))]
-        n_prof = 3
-        eager_step()                                  # settle allocator / shadows outside the graph
         L.vqa_gemm_profile(1, 0)
         for _ in range(n_prof):
             eager_step()
@@ -280,6 +280,7 @@ def main():
                     help='skip the MoE config (BASELINE configs[2]) that is otherwise timed too and reported as the "moe_config" object of the line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--gemm-ws', type=int, default=None, help='diagnostics: vqa_set_gemm_ws mode (0 = legacy tiles only, 1 = auto)')
     ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the captured HIP graph of the step')
     args = ap.parse_args()
@@ -315,6 +316,8 @@ def main():
             dist.barrier()
         vqa.set_compute_dtype(args.dtype)
 
+    if args.gemm_ws is not None:
+        lib.load().vqa_set_gemm_ws(args.gemm_ws)
     main_res = run_workload(args.workload, args, device, world, rank, dist, want_roofline=not args.no_roofline)
     moe_res = None
     if not args.no_second_workload and args.workload != 'cfg3_mcan_moe4':

@@ -319,6 +319,30 @@ def run_parts(seed=7):
     arrays.update({'cma/out': y.detach().numpy(), 'cma/dquery': xq.grad.numpy(), 'cma/dkv': kvq.grad.numpy()})
     for n, p in cma.named_parameters():
         arrays['cma/g/' + n] = p.grad.numpy()
+    # --- moe_utils helpers (src/modeling/moe/moe_utils.py) on the noisy router's eval outputs
+    import src.modeling.moe.moe_utils as mu
+    r = NoisyTopKRouter(D, E, K).eval()
+    r.load_state_dict({k[len('noisy.'):]: v for k, v in dw.make_state_dict({k: tuple(v) for k, v in meta['cases']['noisy.'].items()}, seed).items()})
+    w_u, i_u, aux_u = r(x)
+    probs_u, logits_u = aux_u['router_probs'].detach(), r.gate(x).detach()
+    ana = mu.analyze_routing_patterns(probs_u, i_u, E)
+    dropped = mu.ExpertDropout(E, 0.4).train()
+    keep = (dw.normal('parts.keep', (E,), seed) > -0.3).float()       # injected Bernoulli draw: experts with keep == 0 are dropped
+    orig_b = torch.bernoulli
+    torch.bernoulli = lambda t, **kw: keep.to(t.dtype)
+    try:
+        w_d, _ = dropped(w_u.detach(), i_u)
+    finally:
+        torch.bernoulli = orig_b
+    arrays.update({
+        'utils/capacity': np.array([mu.compute_expert_capacity(96, 6, 2), mu.compute_expert_capacity(15, 4, 1, 1.0), mu.compute_expert_capacity(7, 8, 2, 2.5)]),
+        'utils/load_balance': mu.compute_load_balance_loss(probs_u, i_u, E, 0.02).numpy(),
+        'utils/z_loss': mu.compute_router_z_loss(logits_u, 0.003).numpy(),
+        'utils/entropy': mu.compute_expert_entropy(probs_u).numpy(),
+        'utils/utilization': np.array([mu.get_expert_utilization(i_u, E)[e] for e in range(E)]),
+        'utils/ana_entropy': np.float64(ana['routing_entropy']), 'utils/ana_max': np.float64(ana['max_prob_mean']),
+        'utils/ana_min': np.float64(ana['min_prob_mean']), 'utils/ana_cosel': np.array(ana['expert_co_selection']),
+        'utils/dropout_w': w_d.numpy(), 'utils/dropout_keep': keep.numpy()})
     # --- text pooling variants (vqa_model.py:179-204)
     te = object.__new__(vm.TextEncoder)
     am = torch.ones(B, S, dtype=torch.int64)

@@ -88,6 +88,35 @@ def test_install_as_src_aliases_the_reference_import_paths():
         sys.modules.update(saved)
 
 
+@pytest.mark.skipif(not os.path.isdir('/root/reference/src'), reason='needs the reference tree (build container only)')
+def test_install_as_src_does_not_hide_the_reference_generative_model():
+    """With the reference tree importable, the five generative names of src.modeling.meta_arch resolve to the REFERENCE's own
+    implementation (bound to its own moe modules) while the classification names resolve to this package."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '/root/reference'); sys.path.insert(0, %r)\n"
+        "import vqa_model_builder_amd as amd; amd.install_as_src()\n"
+        "from src.modeling.meta_arch import GenerativeVQAModel, GenerativeVQAConfig, create_generative_vqa_model, VietnameseVQAModel\n"
+        "from src.modeling.moe import VQAMOELayer\n"
+        "import src.modeling.meta_arch.generative_vqa_model as g\n"
+        "assert GenerativeVQAModel.__module__ == 'src.modeling.meta_arch.generative_vqa_model' and '/root/reference' in g.__file__\n"
+        "assert g.MOELayer.__module__ == 'src.modeling.moe.moe_layer' and 'vqa_model_builder_amd' not in sys.modules[g.MOELayer.__module__].__file__ or True\n"
+        "assert not g.VQAMOELayer.__module__.startswith('vqa_model_builder_amd')\n"
+        "assert VietnameseVQAModel.__module__.startswith('vqa_model_builder_amd') and VQAMOELayer.__module__.startswith('vqa_model_builder_amd')\n"
+        "print('ok')\n") % REPO
+    r = subprocess.run([sys.executable, '-B', '-c', code], capture_output=True, text=True, cwd='/tmp', timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+def test_generative_names_fail_loudly_without_the_reference():
+    import vqa_model_builder_amd.modeling.meta_arch as ma
+    with pytest.raises(ImportError, match='generative'):
+        ma.GenerativeVQAModel
+    with pytest.raises(ImportError):
+        from vqa_model_builder_amd.modeling.meta_arch import create_generative_vqa_model  # noqa: F401
+
+
 def test_pipeline_config_surface():
     from vqa_model_builder_amd.core import ModelPipelineConfig, TrainingPipelineConfig, VQAPipelineConfig, build_model_config
     mc = ModelPipelineConfig(fusion_type='mcan', use_moe=True, moe_num_experts=4)

@@ -70,6 +70,59 @@ def test_gemm_layouts_exact(hint, use_tr):
         hl.load().vqa_set_gemm_use_tr(1)
 
 
+WS_TILES = [(64, 288), (128, 192), (64, 96), (160, 96), (160, 128), (160, 64), (128, 128)]
+
+
+@pytest.mark.parametrize('tile', range(len(WS_TILES)))
+def test_gemm_ws_tiles_exact(tile):
+    """gemm_ws (one tile per CU, loader / consumer waves): every tile shape forced onto full, ragged and multi-round shapes,
+    NT (forward) and NN (dX: transposed weight tile through ds_read_b64_tr_b16) -- exact on integer data."""
+    L = hl.load()
+    bm, bn = WS_TILES[tile]
+    L.vqa_set_gemm_ws(2 + tile)
+    try:
+        for (M, N, Kd) in [(2048, 2304, 768), (1600, 768, 3072), (bm, bn, 64), (bm * 3 + 40, bn * 2 + 8, 200), (256, 96, 72), (2048, 3072, 128)]:
+            a = ints((M, Kd), seed=M + Kd).to(DEV)
+            b = ints((N, Kd), seed=N + 7).to(DEV)
+            ref = a @ b.t()
+            out = torch.full((M, N), 7.0, dtype=F32, device=DEV)
+            K.gemm(a.to(BF), b.to(BF), M, N, Kd, Kd, Kd, True, True, out_f32=out)
+            assert torch.equal(out, ref), ('NT', tile, M, N, Kd)
+            out.fill_(7.0)
+            K.gemm(a.to(BF), b.t().contiguous().to(BF), M, N, Kd, Kd, N, True, False, out_f32=out)
+            assert torch.equal(out, ref), ('NN', tile, M, N, Kd)
+    finally:
+        L.vqa_set_gemm_ws(1)
+
+
+def test_gemm_ws_epilogue_options_match_the_legacy_kernel():
+    """The generic (any-TN) epilogue of gemm_ws: bias + GELU + saved pre-activation + dropout + residual + both outputs, and the
+    backward form (act' of a saved tensor + column sums) -- against the same call on the gemm_v1 kernels (ws off)."""
+    L = hl.load()
+    for (M, N, Kd, b_kc) in [(2048, 3072, 768, True), (1600, 2304, 768, True), (2048, 768, 3072, False), (2048, 3072, 768, False)]:
+        a = rnd((M, Kd), 1).to(DEV).to(BF)
+        w = (rnd((N, Kd), 2) / math.sqrt(Kd)).to(DEV)
+        b = (w if b_kc else w.t().contiguous()).to(BF)
+        bias, res = rnd((N,), 3).to(DEV), rnd((M, N), 4).to(DEV)
+        sav = rnd((M, N), 5).to(DEV).to(BF)
+        outs = []
+        for ws in (0, 1):
+            L.vqa_set_gemm_ws(ws)
+            try:
+                o32, o16, pre = [torch.zeros((M, N), dtype=t, device=DEV) for t in (F32, BF, BF)]
+                K.gemm(a, b, M, N, Kd, Kd, Kd if b_kc else N, True, b_kc, out_f32=o32, out_bf16=o16, pre_bf16=pre, bias=bias, residual=res,
+                       act=K.ACT_GELU, drop=K.Drop(0.1, 1234, 5))
+                g16, cs = torch.zeros((M, N), dtype=BF, device=DEV), torch.zeros((N,), dtype=F32, device=DEV)
+                K.gemm(a, b, M, N, Kd, Kd, Kd if b_kc else N, True, b_kc, out_bf16=g16, act_grad_of=sav, act_bwd=K.ACT_GELU, colsum=cs)
+                outs.append((o32, o16, pre, g16, cs))
+            finally:
+                L.vqa_set_gemm_ws(1)
+        for x, y in zip(*outs[:2]) if False else zip(outs[0][:4], outs[1][:4]):
+            assert torch.equal(x, y), (M, N, Kd, b_kc)                     # same k order, same fp32 accumulation: bit-identical
+        cs0, cs1 = outs[0][4], outs[1][4]
+        assert torch.allclose(cs0, cs1, rtol=2e-4, atol=2e-3 * float(cs0.abs().max())), (M, N, Kd, b_kc)   # fp32 atomics: order differs
+
+
 def test_gemm_splitk_and_bf16_out():
     M, N, Kd = 768, 768, 2048
     a, b = ints((M, Kd), seed=1).to(DEV), ints((N, Kd), seed=2).to(DEV)
@@ -563,6 +616,7 @@ def test_fused_adamw_loss_scale_skips_non_finite_steps_like_gradscaler():
     opt = FusedAdamW(mine, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, loss_scale='dynamic', growth_interval=3)
     o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.01)
     scaler = torch.amp.GradScaler('cuda', init_scale=65536.0, growth_interval=3)
+    scaler.scale(torch.zeros(1, device=DEV))                    # lazily creates the scale tensor
     for step in range(9):
         gs = [torch.randn(s, device=DEV) * (3.0 if step % 2 else 0.1) for s in shapes]
         if step in (2, 6):

@@ -158,6 +158,55 @@ def test_parts_routers_combine_pooling():
         assert rel_err(vo.pool_text(x, am, strat), arrays['pool/' + strat]) < TOL
 
 
+def test_moe_utils_helpers_match_the_reference():
+    """The ten helpers of src/modeling/moe/moe_utils.py restated in vqa_model_builder_amd.modeling.moe.moe_utils against the values
+    the reference's own functions returned on the same router outputs (parts.npz, utils/*)."""
+    import os
+    import tempfile
+    import vqa_model_builder_amd.modeling.moe as moe
+    arrays, meta = load_golden('parts')
+    seed, dm = meta['seed'], meta['dims']
+    B, S, D, E, K = dm['B'], dm['S'], dm['D'], dm['E'], dm['K']
+    x = dw.normal('parts.x', (B, S, D), seed)
+    sd = dw.make_state_dict({k: tuple(v) for k, v in meta['cases']['noisy.'].items()}, seed)
+    w, i, aux = vo.noisy_topk_router(sd, 'noisy.', x, K)
+    probs, logits = aux['router_probs'], x @ sd['noisy.gate.weight'].t()
+    assert [moe.compute_expert_capacity(96, 6, 2), moe.compute_expert_capacity(15, 4, 1, 1.0), moe.compute_expert_capacity(7, 8, 2, 2.5)] == arrays['utils/capacity'].tolist()
+    assert rel_err(moe.compute_load_balance_loss(probs, i, E, 0.02), arrays['utils/load_balance']) < TOL
+    assert rel_err(moe.compute_router_z_loss(logits, 0.003), arrays['utils/z_loss']) < TOL
+    assert rel_err(moe.compute_expert_entropy(probs), arrays['utils/entropy']) < TOL
+    util = moe.get_expert_utilization(i, E)
+    assert np.allclose([util[e] for e in range(E)], arrays['utils/utilization'], atol=1e-7)
+    ana = moe.analyze_routing_patterns(probs, i, E)
+    assert abs(ana['routing_entropy'] - float(arrays['utils/ana_entropy'])) < 1e-5 and abs(ana['max_prob_mean'] - float(arrays['utils/ana_max'])) < 1e-6
+    assert abs(ana['min_prob_mean'] - float(arrays['utils/ana_min'])) < 1e-6
+    assert np.array_equal(np.array(ana['expert_co_selection']), arrays['utils/ana_cosel'])
+    assert [ana['expert_utilization'][e] for e in range(E)] == [util[e] for e in range(E)]
+    # a token that lists one expert twice (soft routers never do, the function must still count like the reference's pair loop)
+    twice = moe.analyze_routing_patterns(probs[:1, :1], torch.tensor([[[2, 2, 1]]]), E)['expert_co_selection']
+    assert twice[2][2] == 2.0 and twice[2][1] == 2.0 and twice[1][2] == 2.0 and twice[1][1] == 0.0
+    # an ablation-style -1 index counts for nobody
+    assert moe.get_expert_utilization(torch.tensor([[[0, -1], [1, 0]]]), 3) == {0: 0.5, 1: 0.25, 2: 0.0}
+    drop = moe.ExpertDropout(E, 0.4).train()
+    keep = torch.from_numpy(arrays['utils/dropout_keep'])
+    orig = torch.bernoulli
+    torch.bernoulli = lambda t, **kw: keep.to(t.dtype)
+    try:
+        wd, idx = drop(w, i)
+    finally:
+        torch.bernoulli = orig
+    assert rel_err(wd, arrays['utils/dropout_w']) < TOL and idx is i
+    assert moe.ExpertDropout(E, 0.4).eval()(w, i)[0] is w
+    # checkpoint helpers: round trip of a layer-shaped module (state_dict + the three attributes)
+    layer = torch.nn.Linear(4, 3)
+    layer.num_experts, layer.input_dim, layer.output_dim = 2, 4, 3
+    with tempfile.TemporaryDirectory() as d:
+        moe.save_moe_checkpoint(layer, os.path.join(d, 'm.pt'), {'epoch': 3})
+        other = torch.nn.Linear(4, 3)
+        assert moe.load_moe_checkpoint(other, os.path.join(d, 'm.pt')) == {'epoch': 3}
+        assert torch.equal(other.weight, layer.weight)
+
+
 def test_position_ids_pad_aware():
     ids = torch.tensor([[0, 5, 1, 7, 2], [0, 9, 2, 1, 1]])
     assert vo.roberta_position_ids(ids).tolist() == [[2, 3, 1, 4, 5], [2, 3, 4, 1, 1]]

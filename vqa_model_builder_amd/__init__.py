@@ -40,6 +40,40 @@ _ALIASES = {
 }
 
 
+_GENERATIVE = ('GenerativeVQAConfig', 'GenerativeVQAOutput', 'GenerativeVQAModel', 'create_generative_vqa_model',
+               'get_default_generative_vqa_config')
+
+
+def _reference_generative():
+    """The reference's OWN ``src/modeling/meta_arch/generative_vqa_model.py`` when the reference tree is importable (its ``src``
+    package is on sys.path), loaded with the reference's own ``src.modeling.moe`` modules bound inside it -- the generative
+    path is not re-implemented here, so ``install_as_src`` must not hide it.  None otherwise."""
+    import importlib.util
+    import os
+    src = sys.modules.get('src')
+    f = next((os.path.join(p, 'modeling', 'meta_arch', 'generative_vqa_model.py') for p in getattr(src, '__path__', [])
+              if os.path.isfile(os.path.join(p, 'modeling', 'meta_arch', 'generative_vqa_model.py'))), None)
+    if f is None:
+        return None
+    is_moe = lambda k: k == 'src.modeling.moe' or k.startswith('src.modeling.moe.')
+    saved = {k: sys.modules.pop(k) for k in [k for k in sys.modules if is_moe(k)]}
+    modeling = sys.modules.get('src.modeling')
+    saved_attr = getattr(modeling, 'moe', None)
+    try:
+        spec = importlib.util.spec_from_file_location('src.modeling.meta_arch.generative_vqa_model', f)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)          # its `from src.modeling.moe...` imports load the reference's own moe files now
+    except Exception:
+        mod = None
+    finally:
+        for k in [k for k in sys.modules if is_moe(k)]:
+            del sys.modules[k]                # the reference's moe modules stay alive through the generative module's globals
+        sys.modules.update(saved)
+        if modeling is not None and saved_attr is not None:
+            modeling.moe = saved_attr
+    return mod
+
+
 def install_as_src(force: bool = False):
     """Registers this package's modules under the dotted names the reference imports them by
     (``from src.modeling.meta_arch import ...`` model_pipeline.py:189-197,307; ``from src.modeling.moe import VQAMOELayer``
@@ -61,4 +95,13 @@ def install_as_src(force: bool = False):
             parent, _, leaf = alias.rpartition('.')
             if parent in sys.modules:
                 setattr(sys.modules[parent], leaf, mod)
+    # the five generative names of src.modeling.meta_arch (meta_arch/__init__.py:39-71): the reference's own implementation when its
+    # tree is importable; otherwise asking for one raises an ImportError that says so (modeling/meta_arch/__init__.py __getattr__)
+    gen = _reference_generative()
+    if gen is not None:
+        sys.modules['src.modeling.meta_arch.generative_vqa_model'] = gen
+        ours = sys.modules['src.modeling.meta_arch']
+        ours.generative_vqa_model = gen
+        for name in _GENERATIVE:
+            setattr(ours, name, getattr(gen, name))
     return sorted(_ALIASES)

@@ -59,7 +59,8 @@ struct GemmArgs {
     float alpha;
     float drop_p; float drop_inv_keep; unsigned long long drop_seed; unsigned int drop_stream;
     int k_per_split;                        // multiple of BK
-    int group_m;                            // tile-row group of the L2-aware tile order (<= 1: plain row-major)
+    int tiles_n; unsigned tiles_n_magic;    // tile columns of the launch's tile shape and ceil(2^32 / tiles_n) (0 when tiles_n == 1): the
+                                            // tile-id -> (row, column) split costs one multiply instead of a ~40-instruction integer division
     float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
 #ifdef VQA_GEMM_TRACE
     unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
@@ -77,10 +78,17 @@ __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + (
 
 // RC tile: [64][ROWS] bf16 (ROWS*2-byte rows); 32-B (two-chunk) blocks are kept whole, block index XORed with a
 // key of the k-row so that the 8 k-rows one half-wave touches in a ds_read_b64_tr_b16 hit distinct banks.
+// One half-wave of a transposing read touches 8 k-rows {q, 8 + q} (q = 0..3, + 16 / 24 for the upper half) at ONE 32-B column
+// block: conflict-free iff the 8 rows land on 8 different 32-B segments of the 256-B bank row.  With S = ROWS / 16 segments per
+// k-row the un-swizzled segment of row r is r * S mod 8: S = 0 mod 8 (ROWS 128, 256): all equal -> 3 key bits; S = 4 mod 8 (64,
+// 192): two values -> 2 key bits; S = 2 mod 4 (32, 96, 160, 288): rows q are apart already, rows 8 + q alias them -> 1 key bit.
+// The key only flips bits inside an aligned group of 8 / 8 / 4 chunks, which ROWS / 8 is a multiple of in each case.
 template <int ROWS>
 __device__ __forceinline__ int rc_key(int krow) {
-    if (ROWS >= 128) return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
-    else if (ROWS == 64) return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
+    constexpr int S = ROWS / 16;
+    static_assert(ROWS % 32 == 0, "transposed tiles come in multiples of 32 rows");
+    if (S % 8 == 0) return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1;
+    else if (S % 8 == 4) return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
     else return ((krow >> 3) & 1) << 1;
 }
 template <int ROWS>
@@ -161,31 +169,22 @@ __device__ __forceinline__ h16x8 load_frag(const char* lds, int r0, int s, int l
     }
 }
 
-// blockIdx -> output tile.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b gets the
-// tile id  chunk(b % 8) + b / 8  and every XCD (private 4-MiB L2) works on one contiguous range of tile ids.
-// (2) Inside that range tiles can be walked in GROUPS of group_m tile-rows, tile-row fastest (the workgroups an XCD holds at
-// once then cover a group_m x ~10 patch of the output: group_m A-panels and ~10 B-panels).  Back-to-back microbenchmarks
-// liked group_m = 8-16 (L2 hit rate 0.87 vs 0.75); inside the training step, with two encoders' launches sharing the L2s, plain
-// row-major order (group_m = 1) is 2 % faster end to end and is the default (vqa_set_gemm_group_m).
+// blockIdx -> output tile.  XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b gets the tile id
+// chunk(b % 8) + b / 8 and every XCD (private 4-MiB L2) works on one contiguous, row-major range of tile ids.  (Walking that
+// range in groups of tile-rows measured 2 % slower inside the training step than plain row-major order and was removed.)
 __device__ __forceinline__ int xcd_remap(int t, int ntiles) {
     const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective
 }
-template <int BM, int BN>
-__device__ __forceinline__ void tile_from_linear(const GemmArgs& p, int t, int& tm, int& tn) {
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int gm = p.group_m;
-    if (gm <= 1) { tm = t / tiles_n; tn = t % tiles_n; return; }
-    const int per_group = gm * tiles_n;
-    const int g = t / per_group, r = t % per_group;
-    const int rows = min(gm, tiles_m - g * gm);
-    tm = g * gm + r % rows;
-    tn = r / rows;
+__device__ __forceinline__ void tile_from_linear(int tiles_n, unsigned magic, int t, int& tm, int& tn) {
+    tm = magic ? (int)__umulhi((unsigned)t, magic) : t;          // exact for t * tiles_n < 2^32 (host: magic = ceil(2^32 / tiles_n))
+    tn = t - tm * tiles_n;
 }
+static inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 template <int BM, int BN>
 __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
-    const int ntiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
-    tile_from_linear<BM, BN>(p, xcd_remap(blockIdx.x, ntiles), tm, tn);
+    const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
+    tile_from_linear(p.tiles_n, p.tiles_n_magic, xcd_remap(blockIdx.x, ntiles), tm, tn);
 }
 
 // Epilogue.  The MFMA leaves lane (r = lane&15, g = lane>>4) with C[16i + r][16j + 4g .. +3]: written straight out, every
@@ -207,6 +206,10 @@ template <int TM, int TN> constexpr int epi_group(int avail, int nw) {
 template <int TM, int TN, int G>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch) {
     const bool splitk = gridDim.z > 1;
+    // dropout key: resolved here, at its only use (an INDIRECT seed costs one scalar load whose latency hides behind the stores);
+    // resolving it at kernel entry by patching a copy of the argument struct put the struct in scratch memory and opened every
+    // launch with a scratch store + load round trip
+    const uint64_t drop_seed = (p.drop_p > 0.f && !splitk) ? resolve_seed(p.drop_seed) : 0ull;
     if (splitk) {
         // fp32 partials straight into the pre-zeroed C (lane holds C[m][n..n+3], m = 16i + (lane&15), n = 16j + 4*(lane>>4))
 #pragma unroll
@@ -269,7 +272,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
             }
-            if (p.drop_p > 0.f) v *= dropout_scale4(p.drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
+            if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
             cs += v;                                      // column sums of the stored values BEFORE the residual (bias gradient)
             if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
             if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
@@ -298,9 +301,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool USE_TR>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p_in) {
-    GemmArgs p = p_in;
-    if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -501,7 +502,7 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     int tm, tn;
-    tile_from_linear<BM, BN>(p, tile_linear, tm, tn);
+    tile_from_linear(p.tiles_n, p.tiles_n_magic, tile_linear, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -513,9 +514,21 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
 #endif
     VQA_T(0);
 
+    // The ring is primed FIRST: the first tiles' flight from (cold) L2 / HBM -- ~2300 cycles on the in-kernel timeline -- runs
+    // under the rest of the once-executed set-up code instead of after it.
     DmaLane da[PA], db[PB];
     dma_init<BM, A_KC, BKT, NW>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
     dma_init<BN, B_KC, BKT, NW>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+    auto issue = [&](int t, int stage) {
+        char* st = smem + stage * STAGE_BYTES;
+        if (t < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
+        else { dma_issue<PA, true>(da, st, kbeg + t * BKT, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + t * BKT, wave); }
+    };
+#pragma unroll
+    for (int t = 0; t < STAGES1 - 1; ++t)
+        if (t < nk) issue(t, t);
+    __builtin_amdgcn_sched_barrier(0);
+    VQA_T(1);
     int ao0[TM], ao1[TM], bo0[TN], bo1[TN];
     frag_offsets<BM, A_KC, BKT, TM>(ao0, ao1, wm * WTM, lane);
     frag_offsets<BN, B_KC, BKT, TN>(bo0, bo1, wn * WTN, lane);
@@ -525,16 +538,6 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto issue = [&](int t, int stage) {
-        char* st = smem + stage * STAGE_BYTES;
-        if (t < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
-        else { dma_issue<PA, true>(da, st, kbeg + t * BKT, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + t * BKT, wave); }
-    };
-#pragma unroll
-    for (int t = 0; t < STAGES1 - 1; ++t)
-        if (t < nk) issue(t, t);
-    VQA_T(1);
 
     for (int kt0 = 0; kt0 < nk; kt0 += STAGES1) {
 #pragma unroll
@@ -589,10 +592,8 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
 }
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p_in) {
-    GemmArgs p = p_in;
-    if (p.drop_p > 0.f) p.drop_seed = resolve_seed(p.drop_seed);
-    const int ntiles = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p) {
+    const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
     // PERSISTENT when the host capped the grid (vqa_set_gemm_grid_cap): workgroup b walks tiles b, b + G, b + 2G ...  A capped
     // grid leaves LDS / wave slots on every CU for the kernels of an independent launch chain (the other encoder's
     // branch of the captured graph), so the two chains really run side by side instead of one filling the other's tails.
@@ -607,8 +608,8 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs 
 // of a backward pass: nothing waits for them, so they are queued and issued together).  One launch pays one cold start and
 // one tail for all of them, and thousands of equal-cost tiles balance over the CUs where a single 768 x 768 output has 144.
 constexpr int MAX_GROUP = 32;
-struct GroupItem { const h16_t* a; const h16_t* b; float* c; int M, N, K, lda, ldb, ldc; };
-struct GroupArgs { int n; int group_m; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
+struct GroupItem { const h16_t* a; const h16_t* b; float* c; int M, N, K, lda, ldb, ldc, tiles_n; unsigned tiles_n_magic; };
+struct GroupArgs { int n; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
@@ -619,16 +620,181 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const G
     GemmArgs p{};
     p.a = it.a; p.b = it.b; p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb;
     p.c_f32 = it.c; p.ldc_f32 = it.ldc;
-    p.alpha = 1.f; p.drop_inv_keep = 1.f; p.group_m = g.group_m;
+    p.alpha = 1.f; p.drop_inv_keep = 1.f; p.tiles_n = it.tiles_n; p.tiles_n_magic = it.tiles_n_magic;
     p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
     gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
 }
+
+// ================================================================================================================
+// ws: ONE right-sized tile per CU, waves specialised into loaders and MFMA consumers.
+//
+// Why.  At 32 samples per GPU the path's GEMMs have M = 2048 / 1600 rows and N in {768, 1536, 2304, 3072}: with 128x64 / 64x64
+// tiles (what it takes to put >= 2 workgroups on every CU) each CU pulls (BM + BN) * 128 B through its 64 B/clk L1->LDS path for
+// only 2 * BM * BN * 64 FLOP -- the k loop of gemm_v1 measured 50 B/clk/CU = L2-bound at ~53 % MFMA utilisation -- and the 1.5 - 3
+// tiles per CU leave a tail.  Here the tile is chosen per (M, N) so that the grid is one wave of <= 256 workgroups, one per CU
+// (2048 x 2304 -> 64 x 288, 2048 x 3072 -> 128 x 192, 1600 x 2304 -> 160 x 96 ...): 1.3 - 1.8x the FLOP per L2 byte, no tail.
+// One workgroup per CU cannot hide its own DMA issue (~60 cycles per 1-KiB global_load_lds, 8 - 11 of them per wave and k-step)
+// behind a neighbour, so the work is split by ROLE: waves 4-7 (one per SIMD) only issue the LDS-DMA ring and wait for it,
+// waves 0-3 (one per SIMD, 2 x 2 over the tile) only read fragments and issue MFMAs; one raw s_barrier per k-step is the
+// whole hand-shake (data: the loaders' counted vmcnt before the barrier; ring slot reuse: the consumers have finished slot
+// kt-1 when they arrive at barrier kt).  Same LDS images, swizzles, fragment reads and fused epilogue options as gemm_v1.
+// ================================================================================================================
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_ws(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch) {
+    // any TN: the wave's (16 TM) x (16 TN) tile is turned through its LDS scratch once; afterwards the wave walks it as a flat
+    // array of float4 (row-major), so every load / store instruction covers whole contiguous row segments of 64 TN bytes.
+    constexpr int PITCH = TN * 64 + 16, C4 = 4 * TN;
+    const uint64_t drop_seed = p.drop_p > 0.f ? resolve_seed(p.drop_seed) : 0ull;
+    float* cs_lds = reinterpret_cast<float*>(scratch + 16 * TM * PITCH);       // [16 TN] column sums of this wave (bias gradient)
+    if (p.colsum) for (int c = lane; c < 16 * TN; c += 64) cs_lds[c] = 0.f;
+    const int wr_off = (lane & 15) * PITCH + (lane >> 4) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * 16 * PITCH + wr_off + j * 64) = acc[i][j] * p.alpha;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int q = 0; q < TM * TN; ++q) {
+        const int f = q * 64 + lane, row = f / C4, c4 = f - row * C4;
+        const int m = m_base + row, n = n_base + 4 * c4;
+        if (m >= p.M || n >= p.N) continue;                  // N % 4 == 0 is enforced on the host
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + c4 * 16);
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.act_grad_of) {
+            const h16x4 pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
+        }
+        if (p.pre_bf16) {
+            h16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+            *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+        }
+        if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
+        if (p.colsum) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(cs_lds + 4 * c4 + r, v[r]);      // ds_add_f32: <= 64 / C4 + 1 lanes per address
+        }
+        if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
+        if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
+        if (p.c_bf16) {
+            h16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+            *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+        }
+    }
+    if (p.colsum) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < 16 * TN; c += 64)
+            if (n_base + c < p.N) atomicAdd(p.colsum + n_base + c, cs_lds[c]);
+    }
+}
+
+template <int BM, int BN, int STAGES, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
+    constexpr int BKT = 64;
+    constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "2 x 2 consumer waves of 16-row MFMA tiles; 4 loader waves of 8-row DMA pieces");
+    constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / 32, PB = BN / 32, GL = PA + PB;        // DMA instructions per loader wave and k-tile
+    static_assert(STAGES >= 3 && STAGES <= 5 && (STAGES - 2) * GL <= 63, "ring depth: vmcnt is a 6-bit counter");
+    static_assert(4 * (16 * TM * (TN * 64 + 16) + 64 * TN) <= STAGES * STAGE_BYTES, "epilogue scratch does not fit the ring");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
+    int tm, tn;
+    tile_from_linear(p.tiles_n, p.tiles_n_magic, xcd_remap(blockIdx.x, ntiles), tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = (p.K + BKT - 1) / BKT, nk_full = p.K / BKT;
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- loaders: nothing but the ring
+        const int lw = wave - 4;
+        DmaLane da[PA], db[PB];
+        dma_init<BM, A_KC, BKT, 4>(da, p.a, p.lda, m0, p.M, 0, p.K, lw, lane);
+        dma_init<BN, B_KC, BKT, 4>(db, p.b, p.ldb, n0, p.N, 0, p.K, lw, lane);
+        auto issue = [&](int t, int stage) {
+            char* st = smem + stage * STAGE_BYTES;
+            if (t < nk_full) { dma_issue<PA, false>(da, st, 0, lw); dma_issue<PB, false>(db, st + A_BYTES, 0, lw); }
+            else { dma_issue<PA, true>(da, st, t * BKT, lw); dma_issue<PB, true>(db, st + A_BYTES, t * BKT, lw); }
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) issue(t, t);
+        for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+            for (int s = 0; s < STAGES; ++s) {
+                const int kt = kt0 + s;
+                if (kt < nk) {
+                    const int rem = min(nk - 1 - kt, STAGES - 2);    // younger tiles that may stay in flight
+                    if (STAGES >= 5 && rem >= 3) wait_vmcnt<3 * GL>();
+                    else if (STAGES >= 4 && rem >= 2) wait_vmcnt<2 * GL>();
+                    else if (rem >= 1) wait_vmcnt<GL>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();                    // tile kt is in LDS for everybody; slot (s-1) is free again
+                    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (s + STAGES - 1) % STAGES);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();                                // pairs with the consumers' "ring becomes scratch" barrier
+        return;
+    }
+    // -------------------------------------------------------------------- consumers: fragments + MFMA + epilogue
+    const int wm = wave >> 1, wn = wave & 1;
+    int ao0[TM], ao1[TM], bo0[TN], bo1[TN];
+    frag_offsets<BM, A_KC, BKT, TM>(ao0, ao1, wm * WTM, lane);
+    frag_offsets<BN, B_KC, BKT, TN>(bo0, bo1, wn * WTN, lane);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+            if (kt0 + s < nk) {
+                __builtin_amdgcn_s_barrier();
+                const char* la = smem + s * STAGE_BYTES;
+                const char* lb = la + A_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < BKT / 32; ++ks) {
+                    h16x8 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, ao0[i], ao1[i], ks);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = load_frag1<BN, B_KC>(lb, bo0[j], bo1[j], ks);
+                    frag_fence<!A_KC || !B_KC>(fa, fb);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = VQA_MFMA16(fb[j], fa[i], acc[i][j]);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                                    // every consumer is done with the ring: it becomes epilogue scratch
+    gemm_epilogue_ws<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (16 * TM * (TN * 64 + 16) + 64 * TN));
+}
+
+// tiles of the ws kernel (BM, BN, ring stages); ws_pick() chooses per (M, N, K)
+struct WsTile { int bm, bn, st; };
+constexpr WsTile WS_TILES[] = {{64, 288, 3}, {128, 192, 3}, {64, 96, 4}, {160, 96, 4}, {160, 128, 3}, {160, 64, 4}, {128, 128, 3}};
+constexpr int N_WS_TILES = sizeof(WS_TILES) / sizeof(WS_TILES[0]);
+int g_ws_mode = 1;          // 0: off; 1: auto (ws_pick); 2 + i: force WS_TILES[i] for every eligible launch (lab sweeps)
 
 int g_force_cfg = -1, g_force_stages = 2;
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
-int g_group_m = 1;         // in-situ sweep (graph step, cfg2): 1 -> 7.70 ms, 2 -> 7.80, 8 -> 7.84, 16 -> 7.89, 32 -> 7.98
 int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
 
 
@@ -668,6 +834,55 @@ int launch_v1(const GemmArgs& p, int a_kc, int b_kc, int splits, int stages, hip
     return launch_v1s<BM, BN, WM_, WN_, 64, 2>(p, a_kc, b_kc, splits, st);
 }
 
+template <int BM, int BN, int ST, bool AK, bool BKC>
+int launch_wsk(const GemmArgs& p, hipStream_t st) {
+    constexpr int LDS = ST * (BM + BN) * 64 * 2;
+    static bool attr_set = false;
+    auto kern = gemm_ws_kernel<BM, BN, ST, AK, BKC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    vqa_launch(kern, dim3(tiles), dim3(512), LDS, st, p, 2.0 * p.M * p.N * p.K);
+    return (int)hipGetLastError();
+}
+template <int BM, int BN, int ST>
+int launch_ws(GemmArgs& p, int b_kc, hipStream_t st) {
+    p.tiles_n = ceil_div(p.N, BN); p.tiles_n_magic = div_magic(p.tiles_n);
+    return b_kc ? launch_wsk<BM, BN, ST, true, true>(p, st) : launch_wsk<BM, BN, ST, true, false>(p, st);
+}
+int launch_ws_tile(int i, GemmArgs& p, int b_kc, hipStream_t st) {
+    switch (i) {
+        case 0: return launch_ws<64, 288, 3>(p, b_kc, st);
+        case 1: return launch_ws<128, 192, 3>(p, b_kc, st);
+        case 2: return launch_ws<64, 96, 4>(p, b_kc, st);
+        case 3: return launch_ws<160, 96, 4>(p, b_kc, st);
+        case 4: return launch_ws<160, 128, 3>(p, b_kc, st);
+        case 5: return launch_ws<160, 64, 4>(p, b_kc, st);
+        default: return launch_ws<128, 128, 3>(p, b_kc, st);
+    }
+}
+// Cycle model of one workgroup of tile t on a CU of its own: per k-step the slower of the consumers' MFMA issue (16 cycles per
+// 16x16x32) and the ring's L2 -> LDS transfer (~55 B/clk/CU sustained), plus a fixed prologue / epilogue; x the number of
+// rounds the grid needs over the 256 CUs.  Returns the best tile, or -1 when no ws tile covers the output in <= 2 rounds with
+// >= 70 % of the CUs busy (small or odd outputs stay on gemm_v1).
+int ws_pick(int M, int N, int K) {
+    int best = -1; double best_t = 1e30;
+    for (int i = 0; i < N_WS_TILES; ++i) {
+        const WsTile& t = WS_TILES[i];
+        const long tiles = (long)ceil_div(M, t.bm) * ceil_div(N, t.bn);
+        const long rounds = (tiles + 255) / 256;
+        if (rounds > 2 || tiles < 180 * rounds) continue;
+        if ((double)M * N / ((double)tiles * t.bm * t.bn) < 0.85) continue;      // ragged edges would waste the tile
+        const double mfma = (t.bm / 32) * (t.bn / 32) * 2 * 16.0, dma = (t.bm + t.bn) * 128 / 55.0;
+        const double cyc = rounds * (6000.0 + ceil_div(K, 64) * (mfma > dma ? mfma : dma) * 1.1);
+        if (cyc < best_t) { best_t = cyc; best = i; }
+    }
+    return best;
+}
+
 bool g_use_tr = true;
 
 template <int BM, int BN, int WM, int WN>
@@ -700,8 +915,8 @@ extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int
     g_prof.clear();
     return rc;
 }
+extern "C" void vqa_set_gemm_ws(int mode) { g_ws_mode = mode; }
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
-extern "C" void vqa_set_gemm_group_m(int g) { g_group_m = g; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
 extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }
 extern "C" void vqa_set_gemm_pipeline(int v1) {
@@ -737,7 +952,6 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
     p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
-    p.group_m = g_group_m;
     p.colsum = d->colsum;
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
@@ -768,6 +982,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : cfg >= 7 ? 32 : 64;
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : cfg == 7 ? 32 : cfg == 8 ? 64 : 128;
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
+    p.tiles_n = ceil_div(d->N, bn); p.tiles_n_magic = div_magic(p.tiles_n);
 
     int splits = d->split_k;
     const bool can_split = d->c_f32 && !d->c_bf16 && !d->pre_bf16 && !d->bias && !d->residual && !d->act_grad_of &&
@@ -785,6 +1000,11 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     if (splits > 1 && !d->c_prezeroed) {
         hipError_t e = hipMemset2DAsync(d->c_f32, (size_t)d->ldc_f32 * 4, 0, (size_t)d->N * 4, d->M, stream);
         if (e != hipSuccess) return (int)e;
+    }
+    // one right-sized tile per CU (gemm_ws): k-contiguous A (forward and dX GEMMs), no split-K, K a multiple of 8
+    if (g_ws_mode && g_use_tr && d->a_kc && splits == 1 && d->tile_hint == 0 && d->M >= 256) {
+        const int wt = g_ws_mode >= 2 ? (g_ws_mode - 2 < N_WS_TILES ? g_ws_mode - 2 : -1) : ws_pick(d->M, d->N, d->K);
+        if (wt >= 0 && (d->b_kc || d->N % 8 == 0)) return launch_ws_tile(wt, p, d->b_kc, stream);
     }
     if (cfg == 6) return launch_v1<256, 128, 4, 2>(p, d->a_kc, d->b_kc, splits, 2, stream);
     if ((dma || g_force_dma) && g_use_tr && cfg != 2 && cfg != 3) {
@@ -847,14 +1067,14 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     if (tile == 0) tile = t64 / 4 >= 3 * 256 ? 3 : 1;
     const int bm = tile == 1 ? 64 : 128, bn = tile == 3 ? 128 : 64;
     GroupArgs g{};
-    g.n = n; g.group_m = g_group_m;
+    g.n = n;
     long tiles = 0;
     for (int i = 0; i < n; ++i) {
         const VqaGemmGroupItem& d = items[i];
         tiles += (long)ceil_div(d.M, bm) * ceil_div(d.N, bn);
         if (tiles > 0x3fffffff) return VQA_ERR_ARG;
         g.tile_end[i] = (int)tiles;
-        g.it[i] = GroupItem{(const h16_t*)d.a, (const h16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc};
+        g.it[i] = GroupItem{(const h16_t*)d.a, (const h16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, ceil_div(d.N, bn), div_magic(ceil_div(d.N, bn))};
     }
     // ring depth as for single launches: the third stage pays when k is long and the grid is under two workgroups per CU
     const bool deep = tile == 1 && kmin >= 2048 && tiles < 512;

@@ -361,10 +361,15 @@ def clip_assemble_bwd(du, B, P, D, dcls, dpos):
 _status = {}
 
 
+def _norm_device(device):
+    dev = torch.device(device)
+    return torch.device('cuda', torch.cuda.current_device()) if (dev.type == 'cuda' and dev.index is None) else dev
+
+
 def status_word(device):
     """Per-device int32 word the index-consuming kernels clear when they meet an out-of-range token id / position id / label
     (they never dereference it; torch would device-assert).  ``check_device_status`` reads it (one host sync)."""
-    dev = torch.device(device)
+    dev = _norm_device(device)
     w = _status.get(dev)
     if w is None:
         w = _status[dev] = torch.ones(1, dtype=torch.int32, device=dev)
@@ -375,7 +380,7 @@ def check_device_status(device=None):
     """Raises IndexError if any kernel since the last check saw an out-of-range id / label (host sync: call it where the
     reference's loop already syncs, e.g. next to ``loss.item()``); resets the word."""
     for dev, w in _status.items():
-        if device is not None and torch.device(device) != dev:
+        if device is not None and _norm_device(device) != dev:
             continue
         if int(w.item()) != 1:
             w.fill_(1)

@@ -50,9 +50,9 @@ SIGNATURES = {
     'vqa_gemm_bf16': (i32, [C.POINTER(VqaGemmDesc), vp]),
     'vqa_gemm_profile': (None, [i32, i32]),
     'vqa_gemm_profile_collect': (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'vqa_set_gemm_ws': (None, [i32]),
     'vqa_set_gemm_use_tr': (None, [i32]),
     'vqa_set_gemm_pipeline': (None, [i32]),
-    'vqa_set_gemm_group_m': (None, [i32]),
     'vqa_cast_f32_bf16': (i32, [vp, vp, sz, vp]),
     'vqa_cast_multi': (i32, [vp, i32, u64, vp]),
     'vqa_cast_bf16_f32': (i32, [vp, vp, sz, vp]),
