@@ -150,7 +150,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
     params = [p for p in model.parameters() if p.requires_grad]
     n_params = sum(p.numel() for p in params)
     # the fused optimiser applies 1/world itself (grad_prescale): the all-reduced SUM is never rescaled in memory
-    reducer = GradReducer(params, average=args.torch_optimizer) if world > 1 else None
+    reducer = GradReducer(params, average=args.torch_optimizer, grad_dtype=args.grad_dtype) if (world > 1 or getattr(args, 'force_segmented', False)) else None
     if world > 1 and not args.torch_optimizer:
         opt.grad_prescale = 1.0 / world
     px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
@@ -180,7 +180,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         batch = dict(pixel_values=px, input_ids=ids, attention_mask=mask, labels=labels)
         ok = 1
         try:
-            graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer,
+            graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer, segmented=True if getattr(args, 'force_segmented', False) else None,
                                        capture_error_mode='thread_local' if world > 1 else 'global')
         except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
             ok = 0
@@ -220,11 +220,12 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
            'launch': launch, 'final_loss': round(float(loss), 4), 'params': n_params}
     if fp16 and hasattr(opt, 'loss_scale'):
         res['loss_scale'] = opt.loss_scale
-    if world > 1:
+    if reducer is not None:
         comm = graphed.comm_stats() if (graphed is not None and hasattr(graphed, 'comm_stats')) else {}
         ranks = torch.ones(1, device=device)
-        dist.all_reduce(ranks)
-        res.update({'ranks_seen': int(ranks.item()), 'allreduce_bytes': reducer.bytes_per_step() if reducer is not None else 0, **comm})
+        if world > 1:
+            dist.all_reduce(ranks)
+        res.update({'ranks_seen': int(ranks.item()), 'allreduce_bytes': reducer.bytes_per_step(), 'grad_dtype': args.grad_dtype, **comm})
 
     if want_roofline:
         # Instrumented re-run of the same step, one launch chain (each GEMM's own duration, not its share of an overlap).  Every
@@ -278,6 +279,7 @@ def main():
                     help="16-bit type of the GEMM / attention operands: bf16 (default) or fp16 (+ dynamic loss scale), the reference loop's autocast dtype")
     ap.add_argument('--no-second-workload', action='store_true',
                     help='skip the MoE config (BASELINE configs[2]) that is otherwise timed too and reported as the "moe_config" object of the line')
+    ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='wire format of the data-parallel gradient exchange')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-ws', type=int, default=None, help='diagnostics: vqa_set_gemm_ws mode (0 = legacy tiles only, 1 = auto)')
@@ -364,6 +366,28 @@ def main():
                                'bytes_per_step': byts, 'traffic': None,
                                'note': 'whole step against the batch-independent parameter traffic (4 + 4 + 30 B/param); activations excluded'}
 
+    # Data-parallel readiness, measured on ONE GPU: the five-graph segmented step (what N > 1 runs) without an exchange gives the
+    # compute side of an N-GPU step; the exchange of the last block (the only exposed one) is modelled from its byte count.
+    dp_model = None
+    if world == 1 and not args.no_second_workload and not args.eager and not args.torch_optimizer:
+        try:
+            args.force_segmented = True
+            seg = run_workload(args.workload, args, device, world, rank, dist, want_roofline=False)
+            args.force_segmented = False
+            BUS = 300e9                           # assumed all-reduce bus bandwidth of an 8-GPU xGMI node (7 links x ~153 GB/s per GPU, ~30 % of it)
+            sb = seg.get('segment_bytes', {})
+            last = sb.get('V', 0)
+            t_last = 2 * (7 / 8) * last / BUS * 1e3
+            dp_model = {'segmented_step_ms_1gpu': seg['ms_per_step'], 'segment_bytes': sb, 'assumed_bus_GBps': BUS / 1e9,
+                        'exposed_allreduce_ms_8gpu_model': round(t_last, 3),
+                        'predicted_8gpu_ms_per_step': round(seg['ms_per_step'] + t_last, 3),
+                        'predicted_8gpu_scaling': round(8 * main_res['ms_per_step'] / (seg['ms_per_step'] + t_last), 2),
+                        'note': 'compute = measured 5-graph step on one GPU (no exchange); + modelled ring time of the LAST block (vision arena): the other '
+                                'blocks travel beside the next block\'s backward; xGMI bus bandwidth is an assumption, not a measurement'}
+        except Exception as e:                       # noqa: BLE001
+            args.force_segmented = False
+            dp_model = {'error': f'{type(e).__name__}: {e}'}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -380,8 +404,8 @@ def main():
                        'global_batch': args.batch * world, 'image': '3x224x224', 'seq_len': 64,
                        'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
                        'launch': main_res['launch'], 'final_loss': main_res['final_loss'],
-                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'exposed_comm_ms', 'comm_ms', 'predicted_8gpu_ms') if k in main_res}},
-            'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res,
+                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'grad_dtype', 'exposed_comm_ms', 'segment_bytes') if k in main_res}},
+            'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res, 'dp_model': dp_model,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -179,11 +179,40 @@ def select_samples(model, dims, num_experts, seed, n_cand, n_keep):
     return idx, (px[idx], ids[idx], mask[idx], labels[idx])
 
 
-def run_model_case(tag, dims, fusion_type, num_experts, seed, full_grads, pool=None, emulate=True):
+def min_relu_margin(model, px, ids, mask):
+    """Smallest |pre-activation| over every nn.ReLU of the reference model (answer head, concat fusion) on this batch: a unit this
+    close to zero is a numerical coin toss at 16-bit operands -- its 0/1 derivative flips and, on a 3-sample fixture, moves the
+    whole gradient by 10-20 % (measured: tiny_concat, seed 11, fp16: ONE of 120 units of classifier.3 at |pre| < 4e-4)."""
+    vals, hooks = [], []
+    for m in model.modules():
+        if isinstance(m, torch.nn.ReLU):
+            hooks.append(m.register_forward_pre_hook(lambda _m, inp: vals.append(float(inp[0].detach().abs().min()))))
+    with torch.no_grad():
+        model(pixel_values=px, input_ids=ids, attention_mask=mask)
+    for h in hooks:
+        h.remove()
+    return min(vals) if vals else float('inf')
+
+
+def run_model_case(tag, dims, fusion_type, num_experts, seed, full_grads, pool=None, emulate=True, relu_margin=None):
+    """``relu_margin`` (tiny fixtures): the seed is advanced in steps of 1000 until no ReLU pre-activation of the reference lies
+    within that distance of zero (fixture margins >> tolerance, as for the answer ids): the seed actually used is stored."""
     model, cfg = build_reference_model(dims, fusion_type, num_experts)
     shapes = dw.shapes_of(model.state_dict())
-    sd = dw.make_state_dict(shapes, seed)
-    model.load_state_dict(sd)
+    for attempt in range(400):
+        sd = dw.make_state_dict(shapes, seed)
+        model.load_state_dict(sd)
+        if relu_margin is None:
+            break
+        px, ids, mask, labels = dw.make_inputs(dims['batch'], dims['seq'], dims['image'],
+                                               vocab_hi=min(30000, dims['vocab']), num_answers=dims['num_answers'], seed=seed)
+        mm = min_relu_margin(model, px, ids, mask)
+        if mm >= relu_margin:
+            print(f'[gen_golden] {tag}: seed {seed} (attempt {attempt}): smallest ReLU pre-activation {mm:.3e}')
+            break
+        seed += 1000
+    else:
+        raise RuntimeError('no seed with the requested ReLU margin')
     sel = None
     if pool is None:
         px, ids, mask, labels = dw.make_inputs(dims['batch'], dims['seq'], dims['image'],
@@ -367,11 +396,11 @@ def main():
     if args.only in ('all', 'parts'):
         run_parts()
     if args.only in ('all', 'tiny'):
-        run_model_case('tiny_concat', TINY, 'concat', 0, 11, True)
-        run_model_case('tiny_xattn', TINY, 'cross_attention', 0, 12, True)
-        run_model_case('tiny_mcan_moe4', TINY, 'mcan', 4, 13, True)
-        run_model_case('tiny_xattn_moe8', TINY, 'cross_attention', 8, 14, True)
-        run_model_case('tiny_bilinear', TINY, 'bilinear', 0, 15, True)
+        run_model_case('tiny_concat', TINY, 'concat', 0, 11, True, relu_margin=1e-2)
+        run_model_case('tiny_xattn', TINY, 'cross_attention', 0, 12, True, relu_margin=1e-2)
+        run_model_case('tiny_mcan_moe4', TINY, 'mcan', 4, 13, True, relu_margin=1e-2)
+        run_model_case('tiny_xattn_moe8', TINY, 'cross_attention', 8, 14, True, relu_margin=1e-2)
+        run_model_case('tiny_bilinear', TINY, 'bilinear', 0, 15, True, relu_margin=1e-2)
     if args.only in ('all', 'full'):
         run_model_case('full_cfg1_concat', FULL, 'concat', 0, 21, False)
         run_model_case('full_cfg2_xattn', FULL, 'cross_attention', 0, 22, False)

@@ -143,6 +143,44 @@ def test_cross_modal_attention_first_token_only(D, H, B, Sq, Skv):
     print('cma first-token', D, 'out', rl(yg, yo), 'dq', rl(qg.grad, qo.grad), 'dkv', rl(kvg.grad, kvo.grad), 'worst grad', check_grads(m, lv, 'c.'))
 
 
+def test_frozen_block_skips_weight_gradient_gemms_and_keeps_dx():
+    """Reference training strategies freeze whole modules per epoch (training_utils.py:401-455).  A frozen CrossModalAttention whose
+    inputs still need gradients (trainable encoders below a frozen fusion): the block issues NO weight-gradient GEMM -- counted
+    through the library's launch recorder -- its parameters get no gradient, and dquery / dkey_value are bit-identical to the
+    unfrozen block's.  A frozen encoder under a frozen input needs no backward at all (autograd never calls the block)."""
+    import ctypes as C
+    from vqa_model_builder_amd.hip import lib
+    from vqa_model_builder_amd.modeling.meta_arch import CrossModalAttention
+    L = lib.load()
+    D, H, B, Sq, Skv = 768, 8, 4, 64, 50
+    m = CrossModalAttention(D, H, 0.1).eval()
+    load_det(m, 5, 'c.')
+    m = m.to(DEV)
+    q, kv, gy = dw.normal('q', (B, Sq, D), 5).to(DEV), dw.normal('kv', (B, Skv, D), 5).to(DEV), dw.normal('gy', (B, Sq, D), 5).to(DEV)
+
+    def run(frozen):
+        for p in m.parameters():
+            p.requires_grad_(not frozen)
+            p.grad = None
+        qg, kvg = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        y = m(qg, kvg)
+        torch.cuda.synchronize()
+        L.vqa_gemm_profile(1, 0)
+        (y * gy).sum().backward()
+        torch.cuda.synchronize()
+        flop, ms, n = (C.c_double * 1)(), (C.c_double * 1)(), (C.c_int * 1)()
+        L.vqa_gemm_profile_collect(1, flop, ms, n)
+        L.vqa_gemm_profile(0, 0)
+        return qg.grad.clone(), kvg.grad.clone(), flop[0], n[0], [p.grad is not None for p in m.parameters()]
+
+    dq1, dkv1, flop1, n1, has1 = run(False)
+    dq0, dkv0, flop0, n0, has0 = run(True)
+    assert all(has1) and not any(has0)
+    assert torch.equal(dq0, dq1) and torch.equal(dkv0, dkv1)
+    assert n0 == 7 and n1 == 8, (n0, n1)                       # 7 dX GEMMs; the 7 weight gradients are ONE grouped launch
+    assert abs(flop0 / flop1 - 0.5) < 0.02, (flop0, flop1)    # dW = dX in FLOPs for every Linear of the block
+
+
 @pytest.mark.parametrize('fusion_type', ['cross_attention', 'concat', 'mcan'])
 def test_fusion_branches(fusion_type):
     from vqa_model_builder_amd.modeling.meta_arch import FusionConfig, MultimodalFusion

@@ -92,7 +92,7 @@ def test_gemm_ws_tiles_exact(tile):
             K.gemm(a.to(BF), b.t().contiguous().to(BF), M, N, Kd, Kd, N, True, False, out_f32=out)
             assert torch.equal(out, ref), ('NN', tile, M, N, Kd)
     finally:
-        L.vqa_set_gemm_ws(1)
+        L.vqa_set_gemm_ws(0)
 
 
 def test_gemm_ws_epilogue_options_match_the_legacy_kernel():
@@ -116,7 +116,7 @@ def test_gemm_ws_epilogue_options_match_the_legacy_kernel():
                 K.gemm(a, b, M, N, Kd, Kd, Kd if b_kc else N, True, b_kc, out_bf16=g16, act_grad_of=sav, act_bwd=K.ACT_GELU, colsum=cs)
                 outs.append((o32, o16, pre, g16, cs))
             finally:
-                L.vqa_set_gemm_ws(1)
+                L.vqa_set_gemm_ws(0)
         for x, y in zip(*outs[:2]) if False else zip(outs[0][:4], outs[1][:4]):
             assert torch.equal(x, y), (M, N, Kd, b_kc)                     # same k order, same fp32 accumulation: bit-identical
         cs0, cs1 = outs[0][4], outs[1][4]

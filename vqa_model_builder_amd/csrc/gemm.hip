@@ -248,40 +248,58 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * EpiScratch<TN>::BYTES + wr_off + j * 64) = acc[i0 + i][j] * p.alpha;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // NOT unrolled: the body carries every fused option; unrolled TM x 16/RPI times it was ~100 KB of once-executed code
-        // and the epilogue ran at instruction-fetch speed (measured 1000-1500 cycles per store instruction)
+        // ROLLED (the body carries every fused option; unrolled TM x 16/RPI times it was ~100 KB of once-executed code that ran at
+        // instruction-fetch speed -- and even a 4x unrolled chunk measured 6 % slower over the step than this form: at one cold
+        // launch per kernel, code size is time).  The global LOADS of the body (saved activation for act', fp32 residual) are
+        // software-pipelined two rows ahead through three rotating register sets: rolled naively, every iteration sat out its own
+        // dependent L2 / HBM load (~600 cycles x 8 - 16 iterations = the in-kernel timeline's 6300-cycle epilogue).
+        constexpr int NQ = G * 16 / RPI;
+        h16x4 pv0, pv1, pv2; f32x4 rv0, rv1, rv2;
+        auto prefetch = [&](int q, h16x4& pv, f32x4& rv) {
+            const int m = m_base + 16 * i0 + q * RPI + rd_row;
+            if (q < NQ && m < p.M && nok) {
+                if (p.act_grad_of) pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+                if (p.residual) rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n);
+            }
+        };
+#ifndef VQA_EPI_PREFETCH
+#define VQA_EPI_PREFETCH 1      // A/B builds (scratch/ab_build.sh): 0 = every row loads its own operands inside its iteration
+#endif
+        const bool has_loads = p.act_grad_of || p.residual;
+        if (VQA_EPI_PREFETCH && has_loads) { prefetch(0, pv0, rv0); prefetch(1, pv1, rv1); }
 #pragma unroll 1
-        for (int q = 0; q < G * 16 / RPI; ++q) {
+        for (int q = 0; q < NQ; ++q) {
+            if (has_loads) prefetch(VQA_EPI_PREFETCH ? q + 2 : q, VQA_EPI_PREFETCH ? pv2 : pv0, VQA_EPI_PREFETCH ? rv2 : rv0);
             const int row = q * RPI + rd_row;            // 0 .. 16 G - 1 (scratch rows are contiguous across the G strips)
-            f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + col * 4);
             const int m = m_base + 16 * i0 + row;
-            if (m >= p.M || !nok) continue;
-            v += bv;
-            if (p.act_grad_of) {
-                const h16x4 pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+            if (m < p.M && nok) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + col * 4) + bv;
+                if (p.act_grad_of) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
-            }
-            if (p.pre_bf16) {
-                h16x4 o;
+                    for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv0[r], p.act_bwd_kind);
+                }
+                if (p.pre_bf16) {
+                    h16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
-                *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
-            }
-            if (p.act != ACT_NONE) {
+                    for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+                    *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+                }
+                if (p.act != ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
-            }
-            if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
-            cs += v;                                      // column sums of the stored values BEFORE the residual (bias gradient)
-            if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
-            if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
-            if (p.c_bf16) {
-                h16x4 o;
+                    for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+                }
+                if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
+                cs += v;                                  // column sums of the stored values BEFORE the residual (bias gradient)
+                if (p.residual) v += rv0;
+                if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
+                if (p.c_bf16) {
+                    h16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
-                *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+                    for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+                    *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+                }
             }
+            if (VQA_EPI_PREFETCH) { pv0 = pv1; rv0 = rv1; pv1 = pv2; rv1 = rv2; }
         }
         __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
     }
@@ -654,40 +672,54 @@ __device__ __forceinline__ void gemm_epilogue_ws(const GemmArgs& p, f32x4 (&acc)
         for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * 16 * PITCH + wr_off + j * 64) = acc[i][j] * p.alpha;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    constexpr int NQ = TM * TN, NB = NQ % 3 == 0 ? 3 : NQ % 2 == 0 ? 2 : 1;      // chunked like gemm_epilogue: loads first, then use
 #pragma unroll 1
-    for (int q = 0; q < TM * TN; ++q) {
-        const int f = q * 64 + lane, row = f / C4, c4 = f - row * C4;
-        const int m = m_base + row, n = n_base + 4 * c4;
-        if (m >= p.M || n >= p.N) continue;                  // N % 4 == 0 is enforced on the host
-        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + c4 * 16);
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.act_grad_of) {
-            const h16x4 pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+    for (int q0 = 0; q0 < NQ; q0 += NB) {
+        h16x4 pv[NB]; f32x4 rv[NB], vv[NB], bb[NB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
+        for (int u = 0; u < NB; ++u) {
+            const int f = (q0 + u) * 64 + lane, row = f / C4, c4 = f - row * C4;
+            const int m = m_base + row, n = n_base + 4 * c4;
+            const bool ok = m < p.M && n < p.N;              // N % 4 == 0 is enforced on the host
+            vv[u] = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + c4 * 16);
+            bb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias && ok) bb[u] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.act_grad_of && ok) pv[u] = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+            if (p.residual && ok) rv[u] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n);
         }
-        if (p.pre_bf16) {
-            h16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
-            *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
-        }
-        if (p.act != ACT_NONE) {
+        for (int u = 0; u < NB; ++u) {
+            const int f = (q0 + u) * 64 + lane, row = f / C4, c4 = f - row * C4;
+            const int m = m_base + row, n = n_base + 4 * c4;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = vv[u] + bb[u];
+            if (p.act_grad_of) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
-        }
-        if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
-        if (p.colsum) {
+                for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[u][r], p.act_bwd_kind);
+            }
+            if (p.pre_bf16) {
+                h16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(cs_lds + 4 * c4 + r, v[r]);      // ds_add_f32: <= 64 / C4 + 1 lanes per address
-        }
-        if (p.residual) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n); v += rv; }
-        if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
-        if (p.c_bf16) {
-            h16x4 o;
+                for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+                *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+            }
+            if (p.act != ACT_NONE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
-            *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+                for (int r = 0; r < 4; ++r) v[r] = act_fwd(v[r], p.act);
+            }
+            if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
+            if (p.colsum) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(cs_lds + 4 * c4 + r, v[r]);      // ds_add_f32: <= 64 / C4 + 1 lanes per address
+            }
+            if (p.residual) v += rv[u];
+            if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
+            if (p.c_bf16) {
+                h16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (h16_t)v[r];
+                *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+            }
         }
     }
     if (p.colsum) {
@@ -719,6 +751,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
     if (wave >= 4) {
         // ---------------------------------------------------------------- loaders: nothing but the ring
         const int lw = wave - 4;
+#ifdef VQA_GEMM_TRACE
+        unsigned long long trl[32];
+        for (int i = 0; i < 32; ++i) trl[i] = 0;
+        trl[0] = __builtin_readcyclecounter();
+#endif
         DmaLane da[PA], db[PB];
         dma_init<BM, A_KC, BKT, 4>(da, p.a, p.lda, m0, p.M, 0, p.K, lw, lane);
         dma_init<BN, B_KC, BKT, 4>(db, p.b, p.ldb, n0, p.N, 0, p.K, lw, lane);
@@ -730,6 +767,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
             if (t < nk) issue(t, t);
+#ifdef VQA_GEMM_TRACE
+        trl[1] = __builtin_readcyclecounter();
+#endif
         for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
 #pragma unroll
             for (int s = 0; s < STAGES; ++s) {
@@ -740,14 +780,25 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
                     else if (STAGES >= 4 && rem >= 2) wait_vmcnt<2 * GL>();
                     else if (rem >= 1) wait_vmcnt<GL>();
                     else wait_vmcnt<0>();
+#ifdef VQA_GEMM_TRACE
+                    if (kt < 24) trl[2 + kt] = __builtin_readcyclecounter();         // tile kt landed (this loader's share)
+#endif
                     __builtin_amdgcn_s_barrier();                    // tile kt is in LDS for everybody; slot (s-1) is free again
                     if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (s + STAGES - 1) % STAGES);
                 }
             }
         }
         __builtin_amdgcn_s_barrier();                                // pairs with the consumers' "ring becomes scratch" barrier
+#ifdef VQA_GEMM_TRACE
+        if (p.trace && wave == 4 && lane == 0) for (int i = 0; i < 32; ++i) p.trace[(size_t)blockIdx.x * 64 + 32 + i] = trl[i];
+#endif
         return;
     }
+#ifdef VQA_GEMM_TRACE
+    unsigned long long tr[32];
+    for (int i = 0; i < 32; ++i) tr[i] = 0;
+#endif
+    VQA_T(0);
     // -------------------------------------------------------------------- consumers: fragments + MFMA + epilogue
     const int wm = wave >> 1, wn = wave & 1;
     int ao0[TM], ao1[TM], bo0[TN], bo1[TN];
@@ -758,11 +809,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    VQA_T(1);
     for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
 #pragma unroll
         for (int s = 0; s < STAGES; ++s) {
             if (kt0 + s < nk) {
                 __builtin_amdgcn_s_barrier();
+#ifdef VQA_GEMM_TRACE
+                if (kt0 + s < 24) VQA_T(2 + kt0 + s);
+#endif
                 const char* la = smem + s * STAGE_BYTES;
                 const char* lb = la + A_BYTES;
 #pragma unroll
@@ -782,14 +837,28 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
         }
     }
     __builtin_amdgcn_s_barrier();                                    // every consumer is done with the ring: it becomes epilogue scratch
+    VQA_T(26);
     gemm_epilogue_ws<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (16 * TM * (TN * 64 + 16) + 64 * TN));
+#ifdef VQA_GEMM_TRACE
+    VQA_T(27);
+    wait_vmcnt<0>();
+    VQA_T(28);
+    if (p.trace && wave == 0 && lane == 0) {
+        tr[29] = __builtin_amdgcn_s_getreg((31 << 11) | 20);          // XCC_ID
+        for (int i = 0; i < 32; ++i) p.trace[(size_t)blockIdx.x * 64 + i] = tr[i];
+    }
+#endif
 }
 
 // tiles of the ws kernel (BM, BN, ring stages); ws_pick() chooses per (M, N, K)
 struct WsTile { int bm, bn, st; };
 constexpr WsTile WS_TILES[] = {{64, 288, 3}, {128, 192, 3}, {64, 96, 4}, {160, 96, 4}, {160, 128, 3}, {160, 64, 4}, {128, 128, 3}};
 constexpr int N_WS_TILES = sizeof(WS_TILES) / sizeof(WS_TILES[0]);
-int g_ws_mode = 1;          // 0: off; 1: auto (ws_pick); 2 + i: force WS_TILES[i] for every eligible launch (lab sweeps)
+int g_ws_mode = 0;          // 0: off (default); 1: auto (ws_pick); 2 + i: force WS_TILES[i] for every eligible launch (lab sweeps)
+                            // Measured (profiles/r02/gemm_ws.md): back-to-back launches of one shape run 5 - 25 % faster on ws tiles,
+                            // the training step runs SLOWER with them (8.05 vs 7.31 ms): a 135-KB-LDS workgroup owns its CU, so the
+                            // other encoder branch of the captured graph can no longer fill the gaps of this one's launches
+unsigned g_ws_mask = 0xffffffffu;   // auto mode: bit i allows WS_TILES[i]
 
 int g_force_cfg = -1, g_force_stages = 2;
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
@@ -872,6 +941,7 @@ int ws_pick(int M, int N, int K) {
     int best = -1; double best_t = 1e30;
     for (int i = 0; i < N_WS_TILES; ++i) {
         const WsTile& t = WS_TILES[i];
+        if (!((g_ws_mask >> i) & 1u)) continue;
         const long tiles = (long)ceil_div(M, t.bm) * ceil_div(N, t.bn);
         const long rounds = (tiles + 255) / 256;
         if (rounds > 2 || tiles < 180 * rounds) continue;
@@ -915,7 +985,7 @@ extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int
     g_prof.clear();
     return rc;
 }
-extern "C" void vqa_set_gemm_ws(int mode) { g_ws_mode = mode; }
+extern "C" void vqa_set_gemm_ws(int mode) { if (mode >= 0x100) { g_ws_mode = 1; g_ws_mask = (unsigned)(mode >> 8); } else { g_ws_mode = mode; g_ws_mask = 0xffffffffu; } }
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
 extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }

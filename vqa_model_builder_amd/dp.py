@@ -9,34 +9,42 @@ The reference has no multi-device code at all: this is new work, sha
     layout, so data-dependent ``None`` gradients cannot desynchronise the collective;
   * after the reduce, ``p.grad`` is re-pointed at its (averaged) bucket slice -- no copy back; parameters that had
     no gradient on ANY rank keep ``grad = None`` so the optimiser skips them exactly like the reference's would
-    (decided by a tiny all-reduced presence bitmap that rides in the first bucket);
+    (decided by a tiny all-reduced presence bitmap);
   * xGMI is point-to-point (7 links/GPU): buckets are sized in tens of MB so RCCL's direct all-to-all-style
     algorithms keep all links busy, and each bucket's all-reduce is launched asynchronously as soon as it is packed;
-  * overlap (``attach()``): a post-accumulate hook per parameter packs its gradient into the bucket the moment autograd
-    produces it and the bucket goes on the wire when its last expected gradient has arrived -- the answer head / MoE /
-    fusion buckets and the first encoder's buckets travel while the remaining backward still computes; ``finalize()``
-    after ``backward()`` sends whatever is left (zero-filling absent gradients), waits, averages and re-points ``.grad``.
+  * overlap, eager step (``attach()``): a post-accumulate hook per parameter packs its gradient into its bucket the moment
+    autograd produces it; a bucket goes on the wire when the gradients it EXPECTS have arrived.  Expected = every parameter
+    that has had a gradient on any rank in an earlier step (learned from the all-reduced presence bitmap, so all ranks agree):
+    parameters that never get one (RoBERTa's pooler, CLIP's post_layernorm, MultimodalExpert's dead branch -- the first
+    parameters of their encoders in send order) do not hold their bucket, or any later one, back until ``finalize()``;
+  * overlap, captured step (``prepare_static`` / ``reduce_segment``): the backward is cut into per-block HIP graphs
+    (graph.GraphedTrainStep) and each block's gradient arenas are all-reduced IN PLACE while the next block's graph replays;
+    ``grad_dtype='bf16'`` sends bfloat16 copies (half the bytes; fp32 masters stay in the arenas).
 """
 
-from typing import List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ('params', 'offsets', 'numel', 'flat', 'work', 'filled', 'pending')
+    __slots__ = ('params', 'offsets', 'numel', 'flat', 'work', 'filled', 'pending', 'expected')
 
     def __init__(self):
         self.params, self.offsets, self.numel, self.flat, self.work = [], [], 0, None, None
-        self.filled, self.pending = [], 0
+        self.filled, self.pending, self.expected = [], 0, []
 
 
 class GradReducer:
-    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None, average: bool = True):
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None, average: bool = True,
+                 grad_dtype: str = 'fp32'):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.average = average
+        if grad_dtype not in ('fp32', 'bf16'):
+            raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
+        self.grad_dtype = grad_dtype
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets: List[_Bucket] = []
         cur = _Bucket()
@@ -50,6 +58,8 @@ class GradReducer:
             cur.numel += n
         if cur.numel:
             self.buckets.append(cur)
+        for b in self.buckets:
+            b.expected = [True] * len(b.params)               # until the first reduced presence bitmap says otherwise
         self.nparams = sum(len(b.params) for b in self.buckets)
         self._presence = None
         self._where = {}
@@ -59,8 +69,12 @@ class GradReducer:
         self._hooks = []
         self._armed = False
         self._next = 0
+        self._learned = False
+        self.sent_before_finalize = 0                         # diagnostics / tests: buckets on the wire when finalize() was called
+        self._segments = None
+        self._stats = {'bytes': 0}
 
-    # ---- overlap mode ---------------------------------------------------------------------------------------------
+    # ---- overlap mode (eager step) -----------------------------------------------------------------------------------
     def attach(self):
         """Registers the per-parameter hooks (idempotent).  Use ``finalize()`` instead of ``reduce()`` afterwards."""
         if self._hooks or self.world == 1:
@@ -74,7 +88,7 @@ class GradReducer:
         self._ensure(device)
         for b in self.buckets:
             b.filled = [False] * len(b.params)
-            b.pending = len(b.params)
+            b.pending = sum(b.expected)
             b.work = None
         self._next = 0
         self._armed = True
@@ -87,20 +101,25 @@ class GradReducer:
             self._arm(p.grad.device)
         bi, si = self._where[id(p)]
         b = self.buckets[bi]
-        if b.filled[si] or bi < self._next:             # second accumulation in one step (grad accumulation): handled in finalize
-            return
+        if b.filled[si] or bi < self._next:             # second accumulation in one step, or a gradient nobody expected that arrives
+            return                                      # behind its bucket: both are settled in finalize()
         off = b.offsets[si]
         b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
         b.filled[si] = True
-        b.pending -= 1
+        if b.expected[si]:
+            b.pending -= 1
         self._launch_ready()
 
     def _launch_ready(self):
         # Collectives are matched across ranks BY ORDER, and which gradients exist is data dependent (an expert no token
         # was routed to on this rank): buckets therefore go on the wire strictly in index order -- a bucket waits for its
-        # own gradients AND for every earlier bucket; whatever is still held back is sent, in the same order, by finalize().
+        # own EXPECTED gradients AND for every earlier bucket; whatever is still held back is sent, in the same order, by
+        # finalize().  Slots of parameters without a gradient are zeroed before the send.
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
             b = self.buckets[self._next]
+            for si, (p, off) in enumerate(zip(b.params, b.offsets)):
+                if not b.filled[si]:
+                    b.flat[off:off + p.numel()].zero_()
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
 
@@ -112,6 +131,7 @@ class GradReducer:
         device = self.buckets[0].params[0].device
         if not self._armed:
             self._arm(device)
+        self.sent_before_finalize = self._next
         flags = [0.0 if p.grad is None else 1.0 for b in self.buckets for p in b.params]
         for b in self.buckets[self._next:]:          # buckets an absent gradient (here or earlier) kept off the wire, in order
             for si, (p, off) in enumerate(zip(b.params, b.offsets)):
@@ -120,19 +140,59 @@ class GradReducer:
                     view.zero_()
                 elif not b.filled[si]:
                     view.copy_(p.grad.reshape(-1))
+                    b.filled[si] = True
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._next = len(self.buckets)
         self._presence.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
         pres_work = dist.all_reduce(self._presence, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # always LAST in the sequence
         pres_work.wait()
-        self._assign(self._presence.tolist())
+        present = self._presence.tolist()
+        # A parameter nobody expected that got a gradient somewhere (its first ever: e.g. an expert routed to for the first time)
+        # may have produced it AFTER its bucket left on some rank.  Every rank derives the same list from the REDUCED bitmap and the
+        # (rank-consistent) expected set, and contributes what its own bucket send did not contain; the sum is added to the slot.
+        fix, i = [], 0
+        for bi, b in enumerate(self.buckets):
+            for si in range(len(b.params)):
+                if present[i] > 0 and not b.expected[si]:
+                    fix.append((bi, si))
+                i += 1
+        if fix:
+            for b in self.buckets:
+                if b.work is not None:
+                    b.work.wait()
+            parts = []
+            for bi, si in fix:
+                b = self.buckets[bi]
+                p = b.params[si]
+                missed = p.grad is not None and not b.filled[si]
+                parts.append(p.grad.reshape(-1).float() if missed else torch.zeros(p.numel(), dtype=torch.float32, device=device))
+            pack = torch.cat(parts)
+            dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.group)
+            o = 0
+            for bi, si in fix:
+                b = self.buckets[bi]
+                n = b.params[si].numel()
+                b.flat[b.offsets[si]:b.offsets[si] + n].add_(pack[o:o + n])
+                o += n
+        self._learn(present)
+        self._assign(present)
         self._armed = False
+
+    def _learn(self, present):
+        """Expected set := every parameter that has had a gradient on some rank in some step so far (monotone, rank-consistent)."""
+        i = 0
+        for b in self.buckets:
+            for si in range(len(b.params)):
+                b.expected[si] = (present[i] > 0) if not self._learned else (b.expected[si] or present[i] > 0)
+                i += 1
+        self._learned = True
 
     def _assign(self, present):
         scale = 1.0 / self.world if self.average else 1.0
         i = 0
         for b in self.buckets:
-            b.work.wait()
+            if b.work is not None:
+                b.work.wait()
             if scale != 1.0:
                 b.flat.mul_(scale)
             for p, off in zip(b.params, b.offsets):
@@ -153,8 +213,7 @@ class GradReducer:
             return
         device = self.buckets[0].params[0].device
         self._ensure(device)
-        # presence bitmap: which parameters got a gradient on this rank
-        flags, k = [], 0
+        flags = []
         for b in self.buckets:
             for p in b.params:
                 flags.append(0.0 if p.grad is None else 1.0)
@@ -178,59 +237,102 @@ class GradReducer:
         pres_work.wait()
         self._assign(self._presence.tolist())
 
+    # ---- captured step: per-segment in-place exchange ------------------------------------------------------------------
     @torch.no_grad()
-    def prepare_static(self):
-        """HIP-graph mode (graph.GraphedTrainStep), called once after the forward+backward graph was captured: from then on
-        every replay writes the gradients to the SAME addresses.  The block runners' gradient arenas (one storage per encoder /
-        fusion layer, holding every gradient of the block) are all-reduced IN PLACE, whole -- no packing pass, no second copy
-        of 0.9 GB of gradients; the few parameters with a storage of their own are packed into one small buffer and
-        ``p.grad`` re-pointed at it.  The set of present gradients is the capture's (a captured step has no data-dependent
-        control flow)."""
-        by_storage = {}
-        for b in self.buckets:
-            for p in b.params:
-                if p.grad is None:
-                    continue
-                us = p.grad.untyped_storage()
-                by_storage.setdefault(us.data_ptr(), [us, []])[1].append(p)
-        self._inplace, loose = [], []
-        for us, ps in by_storage.values():
-            g0 = ps[0].grad
-            if len(ps) > 1 and all(q.grad.dtype == torch.float32 for q in ps) and us.nbytes() % 4 == 0:
-                self._inplace.append(torch.empty(0, dtype=torch.float32, device=g0.device).set_(us, 0, (us.nbytes() // 4,)))
-            else:
-                loose.extend(ps)
-        self._loose = None
-        if loose:
-            n = sum((q.numel() + 3) // 4 * 4 for q in loose)
-            flat = torch.zeros(n, dtype=torch.float32, device=loose[0].grad.device)
-            dsts, srcs, off = [], [], 0
-            for q in loose:
-                view = flat[off:off + q.numel()]
-                srcs.append(q.grad.reshape(-1))
-                dsts.append(view)
-                q.grad = view.view(q.shape)
-                off += (q.numel() + 3) // 4 * 4
-            self._loose = (flat, dsts, srcs)
+    def prepare_static(self, segment_of: Optional[Dict[int, str]] = None, order: Sequence[str] = ('all',)):
+        """HIP-graph mode (graph.GraphedTrainStep), called once after the backward graphs were captured: from then on every
+        replay writes the gradients to the SAME addresses.  The block runners' gradient arenas (one storage per encoder / fusion
+        layer, holding every gradient of the block) are all-reduced IN PLACE, whole -- no packing pass, no second copy of 0.9 GB
+        of gradients; the few parameters with a storage of their own are packed into one small buffer per segment and ``p.grad``
+        re-pointed at it.  ``segment_of`` maps id(parameter) -> segment name (the backward graph that produces its gradient),
+        ``order`` lists the segments in the order their graphs replay: ``reduce_segment(name)`` exchanges one of them.  The set
+        of present gradients is the capture's (a captured step has no data-dependent control flow)."""
+        self._segments = {}
+        for name in order:
+            by_storage = {}
+            for b in self.buckets:
+                for p in b.params:
+                    if p.grad is None or (segment_of is not None and segment_of.get(id(p), order[0]) != name):
+                        continue
+                    us = p.grad.untyped_storage()
+                    by_storage.setdefault(us.data_ptr(), [us, []])[1].append(p)
+            inplace, loose = [], []
+            for us, ps in by_storage.values():
+                g0 = ps[0].grad
+                if len(ps) > 1 and all(q.grad.dtype == torch.float32 for q in ps) and us.nbytes() % 4 == 0:
+                    inplace.append(torch.empty(0, dtype=torch.float32, device=g0.device).set_(us, 0, (us.nbytes() // 4,)))
+                else:
+                    loose.extend(ps)
+            pack = None
+            if loose:
+                n = sum((q.numel() + 3) // 4 * 4 for q in loose)
+                flat = torch.zeros(n, dtype=torch.float32, device=loose[0].grad.device)
+                dsts, srcs, off = [], [], 0
+                for q in loose:
+                    view = flat[off:off + q.numel()]
+                    srcs.append(q.grad.reshape(-1))
+                    dsts.append(view)
+                    q.grad = view.view(q.shape)
+                    off += (q.numel() + 3) // 4 * 4
+                pack = (flat, dsts, srcs)
+                inplace.append(flat)
+            stage = None
+            if self.grad_dtype == 'bf16':
+                stage = [torch.empty(f.numel(), dtype=torch.bfloat16, device=f.device) for f in inplace]
+            self._segments[name] = {'flats': inplace, 'pack': pack, 'stage': stage, 'works': [],
+                                    'bytes': sum(f.numel() for f in inplace) * (2 if stage is not None else 4)}
+        self._inplace = [f for s in self._segments.values() for f in s['flats']]
         return self
+
+    def pack_segment(self, name: str):
+        """Device-side preparation of a segment's exchange (capturable: the tail of the segment's backward graph): gathers the
+        stand-alone gradients into the segment's pack buffer and, with bf16 buckets, writes the bfloat16 copies to send."""
+        seg = self._segments[name]
+        if seg['pack'] is not None:
+            _, dsts, srcs = seg['pack']
+            torch._foreach_copy_(dsts, srcs)
+        if seg['stage'] is not None:
+            for f, s in zip(seg['flats'], seg['stage']):
+                s.copy_(f)                                   # fp32 -> bf16 (plumbing for the wire format, not model arithmetic)
+
+    @torch.no_grad()
+    def reduce_segment(self, name: str):
+        """Launches the (asynchronous) all-reduce of one segment on the communication stream: it is ordered after everything the
+        current stream has been given so far (the segment's backward graph) and runs beside whatever is enqueued next."""
+        if self.world == 1:
+            return
+        seg = self._segments[name]
+        bufs = seg['stage'] if seg['stage'] is not None else seg['flats']
+        seg['works'] = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in bufs]
+
+    @torch.no_grad()
+    def wait_segment(self, name: str):
+        seg = self._segments[name]
+        for w in seg['works']:
+            w.wait()
+        seg['works'] = []
+        if seg['stage'] is not None:
+            for f, s in zip(seg['flats'], seg['stage']):
+                f.copy_(s)                                   # bf16 sum -> the fp32 arena the optimiser reads
+        if self.average and self.world > 1:
+            for f in seg['flats']:
+                f.mul_(1.0 / self.world)
 
     @torch.no_grad()
     def reduce_static(self):
-        """After every replay of the forward+backward graph: sum (and, with ``average``, scale) the gradients where they lie."""
+        """All segments back to back (no overlap): the round-1 exchange between the backward and the optimiser graph."""
         if self.world == 1:
             return
-        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self._inplace]
-        flats = list(self._inplace)
-        if self._loose is not None:
-            flat, dsts, srcs = self._loose
-            torch._foreach_copy_(dsts, srcs)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            flats.append(flat)
-        for w in works:
-            w.wait()
-        if self.average and self.world > 1:
-            for f in flats:
-                f.mul_(1.0 / self.world)
+        for name in self._segments:
+            self.pack_segment(name)
+            self.reduce_segment(name)
+        for name in self._segments:
+            self.wait_segment(name)
+
+    def segment_bytes(self) -> Dict[str, int]:
+        return {k: v['bytes'] for k, v in (self._segments or {}).items()}
 
     def bytes_per_step(self) -> int:
+        if self._segments:
+            return sum(v['bytes'] for v in self._segments.values())
         return sum(b.numel for b in self.buckets) * 4

@@ -1,21 +1,36 @@
-"""Whole-step HIP graph: forward + backward + (clip + AdamW) captured once, replayed every step.
+"""Whole-step HIP graphs: forward + backward + (clip + AdamW) captured once, replayed every step.
 
-The path is ~1,500 short kernel launches per step; issued one by one from Python the host, not the GPU, sets the step
+The path is ~530 short kernel launches per step; issued one by one from Python the host, not the GPU, sets the step
 time.  The MI355X-first answer (task brief: "HIP streams and graphs instead of a tracing compiler") is to capture the
-step once and replay it: no per-launch host cost, and independent branches of the step (the two encoders, weight-gradient
-GEMMs) become parallel branches of the graph, filling CUs that a single short GEMM leaves idle during its cold start and
-its C-tile stores.
+step once and replay it: no per-launch host cost, and independent branches of the step (the two encoders) become
+parallel branches of the graph, filling CUs that a single short GEMM leaves idle during its cold start and its C-tile stores.
 
 What makes a replay a real training step and not a re-run of the captured one:
   * inputs are copied into static device buffers before each replay;
   * dropout / router-noise keys are INDIRECT seeds resolved from a device epoch word that the graph itself advances
     (csrc/common.h ``resolve_seed``), so every replay draws fresh masks and backward regenerates the forward's;
-  * the optimiser's learning rate and step count live in device memory and are advanced inside the graph
-    (``FusedAdamW.make_capturable``), so bias correction and schedules follow the real step number.
+  * the optimiser's learning rate, step count and (fp16 mode) loss scale live in device memory and are advanced inside the
+    graph (``FusedAdamW.make_capturable``), so bias correction, schedules and the GradScaler policy follow the real step.
 Data-dependent host decisions cannot be captured: the MoE layers switch to their dense dispatch (every expert on every
 token, combined with the routing weights -- exact, and free at one token per sample; see modeling/moe/moe_layer.py), and an
-expert no token chose is skipped by the optimiser through a device-side routed-token count instead of a ``grad is None``.  With data parallelism the gradient exchange stays outside the graph (forward+backward is one
-graph, the all-reduce is launched eagerly, the optimiser step is a second graph).
+expert no token chose is skipped by the optimiser through a device-side routed-token count instead of a ``grad is None``.
+
+ONE GPU: one graph for the whole step (two parallel encoder branches, all weight-gradient GEMMs grouped at the end).
+
+DATA PARALLEL (a ``dp.GradReducer`` is given): collectives stay outside captures, so the step is cut where the gradient
+exchange can start -- the autograd graph is severed at the encoder outputs and the step becomes FIVE graphs
+
+    F  both encoders forward (parallel branches)
+    H  fusion + MoE + answer head forward AND backward  -> gradients of the head / fusion / MoE and of the encoder outputs
+    T  text-encoder backward                              (the larger arena: 135 M parameters)
+    V  vision-encoder backward
+    O  clip + AdamW (+ loss-scale update)
+
+and the host replays  F, H, [all-reduce H's arenas], T, [all-reduce T's arena], V, [all-reduce V's arena], wait, O:  every
+``all_reduce`` is asynchronous on RCCL's own stream, ordered after the graph that produced its gradients and running beside
+the next graph, so only the LAST block's exchange (the vision arena, 350 MB fp32 / 175 MB with bf16 buckets) is exposed --
+round 1 exposed all 0.98 GB between one backward graph and the optimiser graph.  ``comm_stats()`` reports the measured
+exposed time; tests/test_dp_gpu.py checks the segmented step against the eager data-parallel step.
 """
 
 from typing import Callable, Dict, Optional
@@ -28,16 +43,17 @@ from .hip import blocks as _blocks
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
-                 capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True):
+                 capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
         first backward, and a node bound to the legacy default stream cannot be joined into a capture ("capturing stream has
-        unjoined work") -- the same rule as PyTorch's whole-network capture recipe; the warm-up here runs on a side stream.  ``loss_of(output)`` picks the
-        scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer`` in NON-overlap mode.
-        ``parallel_towers``: the vision encoder runs as a parallel branch of the graph (measured on MI355X, cfg2, B=32:
-        13.7 -> 10.6 ms/step).  ``defer_wgrad``: the weight-gradient GEMMs of both encoders are issued (grouped) after
-        backward returned, where they run alone at full efficiency."""
+        unjoined work") -- the same rule as PyTorch's whole-network capture recipe; the warm-up here runs on a side stream.
+        ``loss_of(output)`` picks the scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer``
+        without hooks attached.  ``parallel_towers``: the vision encoder runs as a parallel branch (measured on MI355X, cfg2,
+        B=32: 13.7 -> 10.6 ms/step).  ``defer_wgrad``: weight-gradient GEMMs are issued grouped at the end of their graph.
+        ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
+        ``forward_from_features``): the five-graph data-parallel step described in the module docstring."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.loss_of = loss_of or (lambda out: out.loss)
         self.static = {k: v.clone() for k, v in batch.items()}
@@ -49,12 +65,20 @@ class GraphedTrainStep:
             if hasattr(m, 'enable_dense_dispatch'):
                 m.enable_dense_dispatch(True)
         self._defer_wgrad = defer_wgrad
+        can_segment = hasattr(model, 'encode_both') and hasattr(model, 'forward_from_features')
+        if segmented is None:
+            segmented = reducer is not None and getattr(reducer, 'world', 1) > 1 and can_segment
+        self.segmented = bool(segmented and can_segment and reducer is not None)
+        self._exposed_ms, self._comm_events, self._replays = [], None, 0
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):                      # warm-up off the default stream (allocator pools, lazy tables, tile attributes)
             for _ in range(max(1, warmup)):    # at least one eager step in the capture's own configuration (streams, dense MoE dispatch)
-                self._fwd_bwd()
+                if self.segmented:
+                    self._segment_F(); self._segment_H(); self._segment_T(); self._segment_V()
+                else:
+                    self._fwd_bwd()
                 if reducer is not None:
                     reducer.reduce()
                 self.opt.step()
@@ -64,13 +88,14 @@ class GraphedTrainStep:
             self.opt.make_capturable(dev)
         self.g_main = torch.cuda.CUDAGraph()
         self.g_opt = None
+        self.graphs = {}
         # capture_error_mode 'thread_local' when other threads may touch the device during the capture (the process group's
         # watchdog polls events)
         if reducer is None:
             with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode, stream=capture_stream):
                 self.loss = self._fwd_bwd()
                 self.opt.step()
-        else:
+        elif not self.segmented:
             with torch.cuda.graph(self.g_main, capture_error_mode=capture_error_mode):
                 self.loss = self._fwd_bwd()
             # the gradients now have their final, static addresses: the reducer finds the arenas it will all-reduce in place
@@ -80,6 +105,37 @@ class GraphedTrainStep:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=capture_error_mode):
                 self.opt.step()
+        else:
+            kw = dict(capture_error_mode=capture_error_mode)
+            with torch.cuda.graph(self.g_main, **kw):                      # F
+                self._segment_F()
+            pool = self.g_main.pool()
+            order = ('H', 'T', 'V')
+            for name, fn in (('H', self._segment_H), ('T', self._segment_T), ('V', self._segment_V)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, **kw):
+                    fn()
+                self.graphs[name] = g
+            seg_of = {}
+            for n, p in model.named_parameters():
+                seg_of[id(p)] = 'V' if n.startswith('visual_encoder.') else 'T' if n.startswith('text_encoder.') else 'H'
+            reducer.prepare_static(seg_of, order)
+            # the device-side packing of each segment (stand-alone gradients -> pack buffer, bf16 wire copies) is a small graph of
+            # its own, replayed right behind the segment's backward graph
+            for name in order:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, **kw):
+                    reducer.pack_segment(name)
+                self.graphs['pack' + name] = g
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=pool, **kw):
+                self.opt.step()
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    # ---- single-graph step -----------------------------------------------------------------------------------------------
+    def _backward(self, loss):
+        # fp16 mode: the optimiser's device-side loss scale (GradScaler's role) multiplies the loss inside the capture
+        (self.opt.scale_loss(loss) if hasattr(self.opt, 'scale_loss') else loss).backward()
 
     def _fwd_bwd(self):
         from .hip import kernels as K
@@ -89,25 +145,95 @@ class GraphedTrainStep:
         try:
             out = self.model(**self.static)
             loss = self.loss_of(out)
-            # fp16 mode: the optimiser's device-side loss scale (GradScaler's role) multiplies the loss inside the capture
-            (self.opt.scale_loss(loss) if hasattr(self.opt, 'scale_loss') else loss).backward()
+            self._backward(loss)
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
         return loss.detach()
+
+    # ---- the data-parallel segments --------------------------------------------------------------------------------------
+    def _segment_F(self):
+        _blocks.advance_rng_epoch()
+        self.opt.zero_grad(set_to_none=True)
+        s = self.static
+        self._enc = self.model.encode_both(s['pixel_values'], s['input_ids'], s['attention_mask'])
+
+    def _segment_H(self):
+        from .hip import kernels as K
+        s = self.static
+        self._cut = [t.detach().requires_grad_(True) for t in self._enc]          # sever the autograd graph at the encoder outputs
+        prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
+        try:
+            out = self.model.forward_from_features(*self._cut, s['attention_mask'], s.get('labels'))
+            loss = self.loss_of(out)
+            self._backward(loss)
+            K.wgrad_flush_all()
+        finally:
+            K.WGRAD_DEFER_TO_STEP_END = prev_defer
+        self.loss = loss.detach()
+
+    def _encoder_backward(self, idx):
+        from .hip import kernels as K
+        outs = [self._enc[i] for i in idx]
+        grads = [self._cut[i].grad for i in idx]
+        pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+        prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
+        try:
+            if pairs:
+                torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+            K.wgrad_flush_all()
+        finally:
+            K.WGRAD_DEFER_TO_STEP_END = prev_defer
+
+    def _segment_T(self):
+        self._encoder_backward((2, 3))               # (text_pooled, text_sequence)
+
+    def _segment_V(self):
+        self._encoder_backward((0, 1))               # (visual_pooled, visual_spatial)
+
+    def describe(self) -> str:
+        if self.reducer is None:
+            return 'hip-graph (one graph: 2 parallel encoder branches, grouped weight gradients, clip + AdamW)'
+        if not self.segmented:
+            return 'hip-graph forward+backward, eager all-reduce, hip-graph optimiser'
+        return ('5 hip-graphs (encoders fwd | fusion+head fwd+bwd | text bwd | vision bwd | optimiser); each block\'s gradient arena '
+                f'all-reduced ({self.reducer.grad_dtype}) beside the next block\'s graph')
+
+    def comm_stats(self) -> Dict[str, float]:
+        if not self._exposed_ms:
+            return {}
+        self._exposed_ms = [e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in self._exposed_ms]
+        v = sorted(self._exposed_ms)
+        return {'exposed_comm_ms': round(v[len(v) // 2], 3), 'segment_bytes': self.reducer.segment_bytes()}
 
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         if batch is not None:
             for k, v in batch.items():
                 self.static[k].copy_(v, non_blocking=True)
         self.g_main.replay()
-        if self.g_opt is not None:
-            self.reducer.reduce_static()
+        if self.segmented:
+            red = self.reducer
+            for name in ('H', 'T', 'V'):
+                self.graphs[name].replay()
+                self.graphs['pack' + name].replay()
+                red.reduce_segment(name)                 # asynchronous: travels beside the next segment's graph
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()                                 # all compute of the step is enqueued: what follows is exposed exchange
+            for name in ('H', 'T', 'V'):
+                red.wait_segment(name)
+            ev1.record()
+            if len(self._exposed_ms) < 512:
+                self._exposed_ms.append((ev0, ev1))
             for m in self.model.modules():              # an expert is active when ANY rank routed a token to it
                 a = getattr(m, '_active', None)
                 if a is not None and getattr(m, 'dense_dispatch', False):
                     torch.distributed.all_reduce(a)
             self.g_opt.replay()
-        if hasattr(self.opt, 'note_replays'):
-            self.opt.note_replays(1)
+        elif self.g_opt is not None:
+            self.reducer.reduce_static()
+            for m in self.model.modules():
+                a = getattr(m, '_active', None)
+                if a is not None and getattr(m, 'dense_dispatch', False):
+                    torch.distributed.all_reduce(a)
+            self.g_opt.replay()
         return self.loss

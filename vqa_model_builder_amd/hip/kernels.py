@@ -171,10 +171,32 @@ def wgrad_join():
     wgrad_flush()
 
 
+SKIP_WEIGHT_GRADS = False      # set by a block whose parameters are all frozen (requires_grad False): see skip_weight_grads
+
+
+class skip_weight_grads:
+    """Context of a block backward whose parameters are ALL frozen (reference training strategies freeze / unfreeze whole
+    modules per epoch: training_utils.py:401-455) but whose input still needs a gradient: every weight-gradient GEMM of the
+    block is skipped -- a third of its backward FLOPs -- while dX flows on unchanged."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global SKIP_WEIGHT_GRADS
+        self.prev, SKIP_WEIGHT_GRADS = SKIP_WEIGHT_GRADS, self.on or SKIP_WEIGHT_GRADS
+
+    def __exit__(self, *exc):
+        global SKIP_WEIGHT_GRADS
+        SKIP_WEIGHT_GRADS = self.prev
+
+
 def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
     """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path).  ``prezeroed``: ``out``
     is known to be zero (gradient arena), so a split-K launch needs no memset.  With WGRAD_GROUPED (default) and a
     caller-provided ``out`` the GEMM is only queued: the caller must end its backward with wgrad_join()."""
+    if SKIP_WEIGHT_GRADS and out is not None:
+        return out                                      # frozen block: nobody reads this gradient
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=dy_bf16.device)
         gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=False)

@@ -142,7 +142,8 @@ def load(path: str = None):
     # torch ships its own libamdhip64: it must be in the process BEFORE this library is dlopen-ed, so that both bind to
     # the same HIP runtime (otherwise torch's streams / allocations are foreign to our launches: hipErrorNoDevice)
     import torch  # noqa: F401
-    p = path or (LIB_PATH_F16 if _half == 'fp16' else LIB_PATH)
+    # VQA_HIP_LIB: an alternative bf16 build of the same sources (A/B experiments: scratch/ab_build.sh); never set in production
+    p = path or (LIB_PATH_F16 if _half == 'fp16' else os.environ.get('VQA_HIP_LIB', LIB_PATH))
     if not os.path.exists(p):
         raise HipLibraryMissing(
             f'{p} not found: build it with `python -m vqa_model_builder_amd.csrc.build` '

@@ -16,6 +16,7 @@ import torch.nn as nn
 from ...hip import ops
 from ...hip.blocks import CrossModalAttentionRunner
 from ...hip.kernels import ACT_NONE, ACT_RELU, Drop
+from ...hip.kernels import skip_weight_grads as K_skip
 from .backbones import ClipVisionBackbone, RobertaBackbone, _BlockFn, _Weights, _flatten_param_keys, _require_cuda, _split_grads
 from .vqa_config import (AnswerHeadConfig, FusionConfig, KnowledgeConfig, MOEConfig, TextEncoderConfig,  # noqa: F401
                          VisualEncoderConfig, VQAModelConfig)
@@ -225,7 +226,8 @@ class CrossModalAttention(nn.Module):
         return self._runner.forward(query, key_value, qm, km, self.training, first_only=self._first_only)
 
     def _hip_backward(self, saved, dout, needs):
-        G, dq, dkv = self._runner.backward(saved, dout, need_dkv=needs[1])
+        with K_skip(not any(p.requires_grad for _, p in self._flat)):     # frozen fusion layer: dX only, no weight-gradient GEMMs
+            G, dq, dkv = self._runner.backward(saved, dout, need_dkv=needs[1])
         return [dq if needs[0] else None, dkv], _split_grads(self._flat, G)
 
     def forward(self, query, key_value, query_mask=None, kv_mask=None, first_token_only=False):
@@ -363,6 +365,12 @@ class VietnameseVQAModel(nn.Module):
 
     def forward(self, pixel_values, input_ids, attention_mask, questions: Optional[List[str]] = None,
                 labels: Optional[torch.Tensor] = None, return_features: bool = False) -> VQAOutput:
+        visual_pooled, visual_spatial, text_pooled, text_sequence = self.encode_both(pixel_values, input_ids, attention_mask)
+        return self.forward_from_features(visual_pooled, visual_spatial, text_pooled, text_sequence, attention_mask, labels, return_features)
+
+    def encode_both(self, pixel_values, input_ids, attention_mask):
+        """(visual_pooled, visual_spatial, text_pooled, text_sequence): the two encoders, on parallel HIP streams when
+        ``parallel_towers`` is set."""
         if getattr(self, 'parallel_towers', False) and pixel_values.is_cuda:
             # The two encoders share nothing until the fusion: run the vision tower on a side HIP stream (its backward
             # follows it there -- autograd replays every node on its forward stream).  A single short GEMM leaves most CUs
@@ -382,6 +390,14 @@ class VietnameseVQAModel(nn.Module):
         else:
             visual_pooled, visual_spatial = self.encode_visual(pixel_values)
             text_pooled, text_sequence = self.encode_text(input_ids, attention_mask)
+        return visual_pooled, visual_spatial, text_pooled, text_sequence
+
+    def forward_from_features(self, visual_pooled, visual_spatial, text_pooled, text_sequence, attention_mask,
+                              labels: Optional[torch.Tensor] = None, return_features: bool = False) -> VQAOutput:
+        """Everything behind the two encoders (reference vqa_model.py:662-727): fusion, MoE, dropout, answer head, loss, argmax.
+        A method of its own so that the data-parallel captured step (graph.GraphedTrainStep) can cut the autograd graph at the
+        encoder outputs: head / fusion backward, text backward and vision backward become separate HIP graphs, and each block's
+        gradient all-reduce travels while the next block's backward computes."""
         fused = self.fusion(visual_spatial, text_sequence, text_mask=~attention_mask.bool())
         moe_info = None
         if self.moe_layer is not None:
