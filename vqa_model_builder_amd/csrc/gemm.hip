@@ -263,7 +263,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
         };
 #ifndef VQA_EPI_PREFETCH
-#define VQA_EPI_PREFETCH 1      // A/B builds (scratch/ab_build.sh): 0 = every row loads its own operands inside its iteration
+#define VQA_EPI_PREFETCH 0      // 1 = two-rows-ahead software-pipelined loads.  A/B inside one gpurun call (scratch/ab_build.sh, bench cfg2, two
+                                // alternating runs each): 7.735 / 7.749 ms with, 7.654 / 7.647 ms without -- the extra registers and moves cost more
+                                // than the hidden latency returns; kept as a build option
 #endif
         const bool has_loads = p.act_grad_of || p.residual;
         if (VQA_EPI_PREFETCH && has_loads) { prefetch(0, pv0, rv0); prefetch(1, pv1, rv1); }
@@ -850,6 +852,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmArgs p) {
 #endif
 }
 
+
 // tiles of the ws kernel (BM, BN, ring stages); ws_pick() chooses per (M, N, K)
 struct WsTile { int bm, bn, st; };
 constexpr WsTile WS_TILES[] = {{64, 288, 3}, {128, 192, 3}, {64, 96, 4}, {160, 96, 4}, {160, 128, 3}, {160, 64, 4}, {128, 128, 3}};
@@ -952,6 +955,7 @@ int ws_pick(int M, int N, int K) {
     }
     return best;
 }
+
 
 bool g_use_tr = true;
 
