@@ -181,6 +181,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         ok = 1
         try:
             graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer, segmented=True if getattr(args, 'force_segmented', False) else None,
+                                       moe_branches=1 if args.moe_branches is None else args.moe_branches,
                                        capture_error_mode='thread_local' if world > 1 else 'global')
         except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
             ok = 0
@@ -283,6 +284,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-ws', type=int, default=None, help='diagnostics: vqa_set_gemm_ws mode (0 = legacy tiles only, 1 = auto)')
+    ap.add_argument('--fused-attn', type=int, default=None, help='diagnostics: bit 0 = fused in-projection + attention in the fusion block, bit 1 = in the encoders (default: both)')
+    ap.add_argument('--expert-runners', type=int, default=None, help='diagnostics: 0 = MoE experts as op-by-op chains (hip/ops.py) instead of the runners')
+    ap.add_argument('--moe-branches', type=int, default=None, help='diagnostics: MoE experts on side streams in the captured step (0 off, 1 specialised experts, 2 every expert)')
     ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the captured HIP graph of the step')
     args = ap.parse_args()
@@ -320,6 +324,12 @@ def main():
 
     if args.gemm_ws is not None:
         lib.load().vqa_set_gemm_ws(args.gemm_ws)
+    if args.fused_attn is not None:
+        from vqa_model_builder_amd.hip import kernels as _K
+        _K.FUSED_ATTENTION_FUSION, _K.FUSED_ATTENTION_ENCODERS = bool(args.fused_attn & 1), bool(args.fused_attn & 2)
+    if args.expert_runners is not None:
+        from vqa_model_builder_amd.modeling.moe import experts as _E
+        _E.EXPERT_RUNNERS = bool(args.expert_runners)
     main_res = run_workload(args.workload, args, device, world, rank, dist, want_roofline=not args.no_roofline)
     moe_res = None
     if not args.no_second_workload and args.workload != 'cfg3_mcan_moe4':

@@ -175,6 +175,30 @@ int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s);
 void vqa_set_attention_mfma(int on);       /* 1 (default): MFMA kernel for Sq,Skv <= 64, Dh in {32,64,96,128}; 0: generic kernel only */
 int vqa_attention_bwd(const VqaAttnDesc* d, vqa_stream_t s);
 
+/* ---- fused in-projection + attention, forward (the x1 row of SURVEY section 8) ---------------------------------
+ * nn.MultiheadAttention up to (not including) its out-projection in ONE launch (reference vqa_model.py:300 self-attention and :304
+ * cross-attention of CrossModalAttention; the encoders' self-attention has the same shape): workgroup (sample b, head h) projects
+ * that head's Q from xq's rows and K | V from xkv's rows with the packed in_proj weight (MFMA, LDS-DMA ring), keeps the three
+ * [64 x Dh] tiles in LDS and runs softmax(Q K^T / sqrt(Dh) + key_padding) V on them.  The projections reach HBM only as the
+ * optional q / k / v copies backward needs (bf16, head h at columns [h*Dh, (h+1)*Dh)); results equal vqa_gemm_bf16 (bias, bf16
+ * out) followed by vqa_attention_fwd bit for bit.  Covered: Dh = D / H in {64, 96}, Sq, Skv <= 64, D % 64 == 0; anything
+ * else returns VQA_ERR_ARG (callers keep the two-launch form for it). */
+typedef struct VqaFusedAttnDesc {
+    const void* xq; int ldxq;            /* bf16 [B*Sq, ldxq]: rows the queries are projected from */
+    const void* xkv; int ldxkv;          /* bf16 [B*Skv, ldxkv]: rows the keys / values are projected from (== xq: self-attention) */
+    const void* w_in; int ldw;           /* bf16 packed in_proj weight [3D, D] (q | k | v row blocks, torch layout), k-contiguous */
+    const float* b_in;                   /* fp32 [3D] or NULL */
+    void* q; void* k; void* v;           /* optional bf16 outputs [B*Sq, ldq] / [B*Skv, ldk] / [B*Skv, ldv] */
+    int ldq, ldk, ldv;
+    void* o; int ldo;                    /* bf16 [B*Sq, ldo]: attention output (input of the out-projection) */
+    int B, H, Sq, Skv, D;
+    const uint8_t* key_padding_mask;     /* uint8 [B, Skv], 1 = ignore; or NULL */
+    float scale;                         /* 0 => Dh^-0.5 */
+    float drop_p; uint64_t drop_seed; uint32_t drop_stream;     /* dropout on the probabilities, keyed as in vqa_attention_fwd */
+} VqaFusedAttnDesc;
+int vqa_fused_inproj_attention_fwd(const VqaFusedAttnDesc* d, vqa_stream_t s);
+
+
 /* ---- RoBERTa embeddings (HF RobertaEmbeddings: word + type0 + pad-aware positions, LN) --------------------- */
 /* pos_ids out: int32 [B,S] = cumsum(ids != pad) * (ids != pad) + pad.  u = sum of the three rows (fp32).
  * V / Pmax: rows of the word / position tables.  An id outside [0,V) or a position id >= Pmax (nn.Embedding: error) is never
@@ -224,6 +248,34 @@ int vqa_moe_combine_bwd(const float* dout, const float* y, const int32_t* list, 
                         float* dw_tok, int n, int D, vqa_stream_t s);
 /* dweights[t,k] = dw_all[indices[t,k], t] */
 int vqa_moe_route_weight_grad(const float* dw_all, const int64_t* indices, float* dweights, int T, int E, int K, vqa_stream_t s);
+
+/* Dense dispatch (captured-graph mode, moe_layer.py:151-168 exactly as the reference runs it: every expert on every token, combined
+ * with weights that are 0 where an expert was not chosen): out[t,:] = sum_e w_all[e,t] * ys[e][t,:] in one launch (w_all [E,T] as
+ * vqa_moe_expert_tokens writes it), and its backward dys[e][t,:] = w_all[e,t] * dout[t,:], dw_all[e,t] = <dout[t,:], ys[e][t,:]>.
+ * ys / dys: HOST arrays of E <= 16 device pointers. */
+int vqa_moe_dense_combine_fwd(const float* const* ys, const float* w_all, float* out, int T, int E, int D, vqa_stream_t s);
+int vqa_moe_dense_combine_bwd(const float* dout, const float* const* ys, const float* w_all, float* const* dys, float* dw_all, int T, int E, int D,
+                              vqa_stream_t s);
+
+/* ---- row kernels of the expert runners (expert_types.py:159-199,270-312,395-445, specialized_experts.py:119-173 at one token per
+ * sample): each replaces a chain of cast / fill / elementwise / column-sum launches on tensors of <= a few hundred rows ------- */
+/* out_bf16[m,n] = dy[m*ld+n] * act'(pre[m,n]) * dropmask(m*N+n)  and  colsum[n] += sum_m out (optional; fp32, pre-zeroed): the
+ * backward of y = drop(act(pre)) + the bias gradient of the Linear that produced pre, in one pass (M small). */
+int vqa_rows_mask_cast(const float* dy, int ld, const void* pre_bf16, int act, void* out_bf16, float* colsum, int M, int N, float p,
+                       uint64_t seed, uint32_t stream, vqa_stream_t s);
+/* nn.MultiheadAttention over ONE key per sample: softmax == 1, the context is V times the dropout keep-scale of the (sample, head,
+ * query) probability.  fwd: out[(t*R + r), :] = v[t, :] * keep(t, head, r)  (R queries per sample; p == 0: a plain broadcast);
+ * bwd: dv[t, :] = sum_r dout[(t*R + r), :] * keep(t, head, r).  bf16 in / out, keyed like vqa_attention_fwd's element (b, h, q, 0). */
+int vqa_head_keep_fwd(const void* v, void* out, int T, int R, int H, int Dh, float p, uint64_t seed, uint32_t stream, vqa_stream_t s);
+int vqa_head_keep_bwd(const void* dout, void* dv, int T, int R, int H, int Dh, float p, uint64_t seed, uint32_t stream, vqa_stream_t s);
+/* dst row i = alpha * src row (mode 0: i / R, every source row R times; mode 1: i % R, the R source rows tiled); fp32 and/or bf16 */
+int vqa_repeat_rows_f32(const float* src, float* dst, void* dst_bf16, int out_rows, int D, int R, int mode, float alpha, vqa_stream_t s);
+/* out[t, :] = mean of rows t*R .. t*R+R-1 of x (fp32 [T*R, D]); fp32 and/or bf16 with row pitch ld_out */
+int vqa_rows_mean_f32(const float* x, int R, float* out, void* out_bf16, int ld_out, int T, int D, vqa_stream_t s);
+/* dst[i] = src[i*stride + offset] (bf16) / dst[i*stride + offset] = src[i] (fp32): the centre tap of a Conv1d(k=3) weight, which is
+ * all a length-1 sequence ever multiplies (specialized_experts.py:66-71 at S = 1), and its gradient's way back */
+int vqa_take_stride_bf16(const void* src, void* dst, size_t n, int stride, int offset, vqa_stream_t s);
+int vqa_scatter_stride_f32(const float* src, float* dst, size_t n, int stride, int offset, vqa_stream_t s);
 /* counter-RNG helpers: N(0,1) noise for the noisy router; stand-alone inverted dropout (vqa_model.py:705) */
 int vqa_randn_f32(float* out, uint64_t n, uint64_t seed, uint32_t stream, vqa_stream_t s);
 int vqa_dropout_f32(const float* x, float* y, void* y_bf16, uint64_t n, float p, uint64_t seed, uint32_t stream, vqa_stream_t s);

@@ -230,6 +230,109 @@ def test_moe_layer(D, Hm, B, E):
     print('moe', D, B, 'out', rl(mg, mo), 'dx', rl(xg.grad, xo.grad), 'worst', check_grads(moe, lv, 'moe_layer.'))
 
 
+def _expert_classes():
+    from vqa_model_builder_amd.modeling.moe import experts as E
+    return E, [E.VisionExpert, E.TextExpert, E.MultimodalExpert, E.SegmentationExpert]
+
+
+@pytest.mark.parametrize('D,Hm,B', [(64, 128, 5), (64, 128, 16), (768, 2048, 32)])
+def test_expert_runners_match_the_op_by_op_chains(D, Hm, B):
+    """Each expert at one token per row as ONE hand-scheduled autograd node (hip/expert_blocks.py: fused epilogues, attention
+    over a single key reduced to out_proj(V), centre-tap convolutions, no cast / fill launches) against the op-by-op chain of
+    hip/ops.py it replaces -- itself pinned to the oracle by test_moe_layer: output, input gradient and every parameter
+    gradient (q / k rows of the one-key attention in-projections: exact zeros on both paths)."""
+    E, classes = _expert_classes()
+    for ci, cls in enumerate(classes):
+        ex = cls(input_dim=D, hidden_dim=Hm, output_dim=D, expert_id=0, dropout=0.1).eval()
+        load_det(ex, 20 + ci, 'e.')
+        ex = ex.to(DEV)
+        x = dw.normal('x', (B, 1, D), 20 + ci).to(DEV)
+        gy = dw.normal('gy', (B, 1, D), 21 + ci).to(DEV)
+        res = {}
+        for runners in (False, True):
+            E.EXPERT_RUNNERS = runners
+            try:
+                for p in ex.parameters():
+                    p.grad = None
+                xg = x.clone().requires_grad_(True)
+                y = ex(xg)
+                (y * gy).sum().backward()
+                res[runners] = (y.detach(), xg.grad, {n: (None if p.grad is None else p.grad.clone()) for n, p in ex.named_parameters()})
+            finally:
+                E.EXPERT_RUNNERS = True
+        (y0, dx0, g0), (y1, dx1, g1) = res[False], res[True]
+        assert rl(y1, y0.cpu()) <= 2e-3, (cls.__name__, rl(y1, y0.cpu()))
+        assert rl(dx1, dx0.cpu()) <= 1e-2, (cls.__name__, rl(dx1, dx0.cpu()))
+        gmax = max(float(g.norm()) for g in g0.values() if g is not None)
+        worst = (0.0, '')
+        for n in g0:
+            if g0[n] is None:
+                assert g1[n] is None or float(g1[n].abs().max()) == 0.0, (cls.__name__, n)
+                continue
+            assert g1[n] is not None, (cls.__name__, n)
+            if float(g0[n].norm()) < 1e-4 * gmax:
+                assert float(g1[n].norm()) <= 1e-2 * gmax, (cls.__name__, n)
+                continue
+            e = rl(g1[n], g0[n].cpu())
+            worst = max(worst, (e, n))
+            assert e <= 1.5e-2, (cls.__name__, n, e)
+        for n, g in g1.items():                    # one-key attention: the q / k thirds of in_proj get exact zeros
+            if n.endswith('in_proj_weight') and 'self_attn' not in n and g is not None and 'cross_attention' not in n:
+                Hh = g.shape[1]
+                assert float(g[:2 * Hh].abs().max()) == 0.0, (cls.__name__, n)
+        print('expert runner', cls.__name__, D, B, 'out', rl(y1, y0.cpu()), 'dx', rl(dx1, dx0.cpu()), 'worst', worst)
+
+
+@pytest.mark.parametrize('D,Hm,B', [(64, 128, 16), (768, 2048, 32)])
+def test_expert_runner_training_dropout_is_one_function_forward_and_backward(D, Hm, B):
+    """Training mode (dropout 0.1 on attention probabilities, FFN activations and sub-layer outputs): backward must regenerate the
+    forward's masks.  With the seed pinned the expert is a fixed function, so its analytic directional derivative (input and a
+    weight) must match a central difference of the scalar <out, g> -- a wrong mask anywhere shows as a 10 % error; the eval /
+    train outputs differ (masks are applied) and two calls with one seed agree bit for bit."""
+    from vqa_model_builder_amd.hip import blocks as hb
+    hb.disable_indirect_seeds()                     # seeds come from torch's CPU generator: torch.manual_seed pins the masks
+    E, classes = _expert_classes()
+    for ci, cls in enumerate(classes):
+        ex = cls(input_dim=D, hidden_dim=Hm, output_dim=D, expert_id=0, dropout=0.1)
+        load_det(ex, 30 + ci, 'e.')
+        ex = ex.to(DEV).train()
+        x = dw.normal('x', (B, 1, D), 30 + ci).to(DEV)
+        gy = dw.normal('gy', (B, 1, D), 31 + ci).to(DEV)
+
+        def f(xx):
+            torch.manual_seed(1234)
+            return ex(xx)
+        xg = x.clone().requires_grad_(True)
+        y = f(xg)
+        (y * gy).sum().backward()
+        assert torch.equal(f(x).detach(), y.detach())
+        assert not torch.equal(ex.eval()(x).detach(), y.detach())
+        ex.train()
+        # directions ALONG the analytic gradient (a random direction makes the derivative a random-sign sum in which the bf16
+        # rounding of the perturbed operand does not average out against the signal)
+        eps = 0.05
+        d = xg.grad / xg.grad.norm() * x.norm()
+        num = float(((f(x + eps * d) - f(x - eps * d)) * gy).sum().double()) / (2 * eps)
+        ana = float((xg.grad * d).sum().double())
+        assert abs(num - ana) <= 0.05 * abs(ana), (cls.__name__, num, ana)
+        for pname in ('output_proj.weight', 'input_proj.weight'):
+            p = dict(ex.named_parameters())[pname]
+            dp = p.grad / p.grad.norm() * p.detach().norm()
+            ana = float((p.grad * dp).sum().double())
+            ew = 0.01                      # every element moves coherently along the gradient: a small step keeps the LayerNorm behind it linear
+            with torch.no_grad():
+                p.add_(ew * dp)
+            yp = f(x).detach()
+            with torch.no_grad():
+                p.sub_(2 * ew * dp)
+            ym = f(x).detach()
+            with torch.no_grad():
+                p.add_(ew * dp)
+            num = float(((yp - ym) * gy).sum().double()) / (2 * ew)
+            assert abs(num - ana) <= 0.05 * abs(ana), (cls.__name__, pname, num, ana)
+        print('expert runner dropout', cls.__name__, D, B, 'ok')
+
+
 @pytest.mark.parametrize('D,Hm,B', [(64, 128, 3), (768, 2048, 4)])
 def test_object_detection_expert(D, Hm, B):
     """ObjectDetectionExpert (reference specialized_experts.py:176-308; reachable from 8 experts): 100 learned queries through a

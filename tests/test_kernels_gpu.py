@@ -273,6 +273,52 @@ def test_attention_dropout_consistency():
     assert abs(om - 1.0) < 0.08
 
 
+@pytest.mark.parametrize('B,H,Sq,Skv,D,masked,p', [(3, 8, 64, 64, 768, True, 0.0), (3, 8, 64, 50, 768, False, 0.1), (5, 8, 1, 64, 768, True, 0.1),
+                                                 (2, 12, 50, 50, 768, False, 0.0), (2, 12, 64, 64, 768, True, 0.1), (2, 2, 17, 33, 128, False, 0.0)])
+def test_fused_inproj_attention_matches_gemm_plus_attention_bit_for_bit(B, H, Sq, Skv, D, masked, p):
+    """vqa_fused_inproj_attention_fwd (one workgroup per (sample, head): Q | K | V projection on the LDS-DMA ring, attention on
+    the LDS-resident tiles) == packed in-projection GEMMs (bias, bf16 out) + vqa_attention_fwd: projections AND context equal
+    bit for bit (same k order in the MFMA accumulation, same core), for self-attention, cross-attention with ragged Skv, the
+    single-query form of the last fusion layer and the encoders' Dh = 64 heads; key-padding mask and dropout keyed alike."""
+    Dh = D // H
+    xq = rnd((B * Sq, D), 1).to(DEV).to(BF)
+    xkv = xq if (Sq == Skv and not masked) else rnd((B * Skv, D), 2).to(DEV).to(BF)
+    w = (rnd((3 * D, D), 3) * D ** -0.5).to(DEV).to(BF)
+    b = rnd((3 * D,), 4).to(DEV)
+    mask = None
+    if masked:
+        mask = torch.zeros((B, Skv), dtype=torch.uint8, device=DEV)
+        mask[0, Skv // 2:] = 1
+        mask[-1, -1] = 1
+    drop = K.Drop(p, 1234, 5) if p > 0 else K.NO_DROP
+    _, q_ref, _ = K.linear_fwd(xq, w[:D], b[:D], B * Sq, D, D, want_bf16=True)
+    _, kv_ref, _ = K.linear_fwd(xkv, w[D:], b[D:], B * Skv, 2 * D, D, want_bf16=True)
+    o_ref = K.attention_fwd(q_ref, kv_ref[:, :D], kv_ref[:, D:], D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, mask, drop)
+    assert K.fused_attention_covers(D, H, Sq, Skv)
+    q = torch.full((B * Sq, D), float('nan'), dtype=BF, device=DEV)
+    kv = torch.full((B * Skv, 2 * D), float('nan'), dtype=BF, device=DEV)
+    o = K.fused_inproj_attention_fwd(xq, xkv, w, b, B, H, Sq, Skv, D, mask, drop, q=q, k=kv[:, :D], v=kv[:, D:], ldq=D, ldk=2 * D, ldv=2 * D)
+    torch.cuda.synchronize()
+    assert torch.equal(q, q_ref) and torch.equal(kv, kv_ref)
+    assert torch.equal(o, o_ref)
+    # without the optional projection copies (inference), and without a bias
+    o2 = K.fused_inproj_attention_fwd(xq, xkv, w, b, B, H, Sq, Skv, D, mask, drop)
+    assert torch.equal(o2, o_ref)
+    _, q0, _ = K.linear_fwd(xq, w[:D], None, B * Sq, D, D, want_bf16=True)
+    _, kv0, _ = K.linear_fwd(xkv, w[D:], None, B * Skv, 2 * D, D, want_bf16=True)
+    o0 = K.attention_fwd(q0, kv0[:, :D], kv0[:, D:], D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, mask, drop)
+    assert torch.equal(K.fused_inproj_attention_fwd(xq, xkv, w, None, B, H, Sq, Skv, D, mask, drop), o0)
+
+
+def test_fused_inproj_attention_rejects_uncovered_shapes():
+    B, H, S, D = 2, 4, 100, 128         # Dh = 32, S > 64
+    x = rnd((B * S, D), 1).to(DEV).to(BF)
+    w = rnd((3 * D, D), 2).to(DEV).to(BF)
+    assert not K.fused_attention_covers(D, H, S, S)
+    with pytest.raises(K.HipError):
+        K.fused_inproj_attention_fwd(x, x, w, None, B, H, S, S, D)
+
+
 # ------------------------------------------------------------------------------------------------ front ends
 def test_patchify_and_clip_assemble():
     B, Cc, H, W, ps, D = 3, 3, 64, 96, 16, 32

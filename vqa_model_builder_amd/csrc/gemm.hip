@@ -18,6 +18,7 @@
 // split-K (gridDim.z > 1) accumulates fp32 partials with global_atomic_add_f32 into a pre-zeroed C.
 #include "common.h"
 #include "vqa_hip.h"
+#include "attn_core.h"
 #include <hip/hip_ext.h>
 #include <vector>
 
@@ -957,6 +958,8 @@ int ws_pick(int M, int N, int K) {
 }
 
 
+#include "fused_attn.h"      // fused in-projection + attention forward (uses the ring / fragment helpers above)
+
 bool g_use_tr = true;
 
 template <int BM, int BN, int WM, int WN>
@@ -973,6 +976,28 @@ int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 }
 
 }  // namespace
+
+extern "C" int vqa_fused_inproj_attention_fwd(const VqaFusedAttnDesc* d, vqa_stream_t stream_) {
+    if (!d || !d->xq || !d->xkv || !d->w_in || !d->o || d->B <= 0 || d->H <= 0) return VQA_ERR_ARG;
+    if (d->D % 64 || d->D % d->H) return VQA_ERR_ARG;
+    const int dh = d->D / d->H;
+    if ((dh != 64 && dh != 96) || d->Sq < 1 || d->Sq > 64 || d->Skv < 1 || d->Skv > 64) return VQA_ERR_ARG;
+    if ((d->ldxq | d->ldxkv | d->ldw | d->ldo) % 8 || (((uintptr_t)d->xq | (uintptr_t)d->xkv | (uintptr_t)d->w_in) & 15) || ((uintptr_t)d->o & 7)) return VQA_ERR_ARG;
+    if (d->b_in && ((uintptr_t)d->b_in & 15)) return VQA_ERR_ARG;
+    if ((d->q && (d->ldq % 8 || ((uintptr_t)d->q & 7))) || (d->k && (d->ldk % 8 || ((uintptr_t)d->k & 7))) || (d->v && (d->ldv % 8 || ((uintptr_t)d->v & 7)))) return VQA_ERR_ARG;
+    FusedArgs p{};
+    p.xq = (const h16_t*)d->xq; p.xkv = (const h16_t*)d->xkv; p.w = (const h16_t*)d->w_in; p.bias = d->b_in;
+    p.q = (h16_t*)d->q; p.k = (h16_t*)d->k; p.v = (h16_t*)d->v;
+    p.ldxq = d->ldxq; p.ldxkv = d->ldxkv; p.ldw = d->ldw; p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.D = d->D;
+    MArgs& a = p.a;
+    a.o = (h16_t*)d->o; a.ldo = d->ldo; a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
+    a.mask = d->key_padding_mask;
+    a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)dh);
+    a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+    a.seed = d->drop_seed; a.stream = d->drop_stream;
+    hipStream_t st = (hipStream_t)stream_;
+    return dh == 96 ? launch_fused_attn<96>(p, st) : launch_fused_attn<64>(p, st);
+}
 
 extern "C" void vqa_gemm_profile(int on, int tag) { g_prof_on = on != 0; g_prof_tag = tag; }
 extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches) {

@@ -43,7 +43,8 @@ from .hip import blocks as _blocks
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
-                 capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None):
+                 capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
+                 moe_branches: int = 1):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -52,6 +53,7 @@ class GraphedTrainStep:
         ``loss_of(output)`` picks the scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer``
         without hooks attached.  ``parallel_towers``: the vision encoder runs as a parallel branch (measured on MI355X, cfg2,
         B=32: 13.7 -> 10.6 ms/step).  ``defer_wgrad``: weight-gradient GEMMs are issued grouped at the end of their graph.
+        ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
         ``forward_from_features``): the five-graph data-parallel step described in the module docstring."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
@@ -64,6 +66,7 @@ class GraphedTrainStep:
         for m in model.modules():                      # MoE layers: dispatch without the host read of the routing counts
             if hasattr(m, 'enable_dense_dispatch'):
                 m.enable_dense_dispatch(True)
+                m.parallel_branches = moe_branches            # specialised experts as a parallel branch of the graph (cfg3: 11.1 -> 10.4 ms)
         self._defer_wgrad = defer_wgrad
         can_segment = hasattr(model, 'encode_both') and hasattr(model, 'forward_from_features')
         if segmented is None:
@@ -81,6 +84,7 @@ class GraphedTrainStep:
                     self._fwd_bwd()
                 if reducer is not None:
                     reducer.reduce()
+                    self._sync_routed_counts()
                 self.opt.step()
         cur.wait_stream(side)
         torch.cuda.synchronize()
@@ -224,16 +228,20 @@ class GraphedTrainStep:
             ev1.record()
             if len(self._exposed_ms) < 512:
                 self._exposed_ms.append((ev0, ev1))
-            for m in self.model.modules():              # an expert is active when ANY rank routed a token to it
-                a = getattr(m, '_active', None)
-                if a is not None and getattr(m, 'dense_dispatch', False):
-                    torch.distributed.all_reduce(a)
+            self._sync_routed_counts()
             self.g_opt.replay()
         elif self.g_opt is not None:
             self.reducer.reduce_static()
-            for m in self.model.modules():
-                a = getattr(m, '_active', None)
-                if a is not None and getattr(m, 'dense_dispatch', False):
-                    torch.distributed.all_reduce(a)
+            self._sync_routed_counts()
             self.g_opt.replay()
         return self.loss
+
+    def _sync_routed_counts(self):
+        """Dense MoE dispatch: an expert is updated when ANY rank routed a token to it (its reduced gradient is the same on every
+        rank, so the decision must be too -- the warm-up steps included, they are real training steps)."""
+        if getattr(self.reducer, 'world', 1) <= 1:
+            return
+        for m in self.model.modules():
+            a = getattr(m, '_active', None)
+            if a is not None and getattr(m, 'dense_dispatch', False):
+                torch.distributed.all_reduce(a)

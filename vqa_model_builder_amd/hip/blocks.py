@@ -96,6 +96,36 @@ def _mask_u8(mask_bool):
     return mask_bool.to(torch.uint8).contiguous()
 
 
+def _qkv_attention(xb, w_in, b_in, B, H, S, D, mask_u8, drop, fused):
+    """Self-attention up to the out-projection: (qkv bf16 [B*S, 3D] kept for backward, context bf16 [B*S, D]).  One launch
+    (csrc/fused_attn.h) where the shape is covered, else packed in-projection GEMM + attention kernel."""
+    M = B * S
+    if fused and K.fused_attention_covers(D, H, S, S):
+        qkv = torch.empty((M, 3 * D), dtype=K.HALF(), device=xb.device)
+        ctx = K.fused_inproj_attention_fwd(xb, xb, w_in, b_in, B, H, S, S, D, mask_u8, drop, q=qkv[:, :D], k=qkv[:, D:2 * D], v=qkv[:, 2 * D:],
+                                           ldq=3 * D, ldk=3 * D, ldv=3 * D)
+        return qkv, ctx
+    _, qkv, _ = K.linear_fwd(xb, w_in, b_in, M, 3 * D, D, want_bf16=True)
+    ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, S, S, D // H, mask_u8, drop)
+    return qkv, ctx
+
+
+def _q_kv_attention(xqb, xkvb, w_in, b_in, B, H, Sq, Skv, D, mask_u8, drop):
+    """Attention with queries projected from ``xqb`` [B*Sq, D] and keys / values from ``xkvb`` [B*Skv, D] through one packed
+    in_proj (cross-attention; self-attention of a single query row): (q bf16 [B*Sq, D], kv bf16 [B*Skv, 2D], context)."""
+    Mq, Mkv = B * Sq, B * Skv
+    if K.FUSED_ATTENTION_FUSION and K.fused_attention_covers(D, H, Sq, Skv):
+        q = torch.empty((Mq, D), dtype=K.HALF(), device=xqb.device)
+        kv = torch.empty((Mkv, 2 * D), dtype=K.HALF(), device=xqb.device)
+        ctx = K.fused_inproj_attention_fwd(xqb, xkvb, w_in, b_in, B, H, Sq, Skv, D, mask_u8, drop, q=q, k=kv[:, :D], v=kv[:, D:],
+                                           ldq=D, ldk=2 * D, ldv=2 * D)
+        return q, kv, ctx
+    _, q, _ = K.linear_fwd(xqb, w_in[:D], b_in[:D], Mq, D, D, want_bf16=True)
+    _, kv, _ = K.linear_fwd(xkvb, w_in[D:], b_in[D:], Mkv, 2 * D, D, want_bf16=True)
+    ctx = K.attention_fwd(q, kv[:, :D], kv[:, D:], D, 2 * D, 2 * D, B, H, Sq, Skv, D // H, mask_u8, drop)
+    return q, kv, ctx
+
+
 # ==================================================================================================================
 # CLIP ViT vision tower (pre-LN, quick-GELU)     reference: vqa_model.py:103-131 -> HF CLIPVisionModel
 # ==================================================================================================================
@@ -120,8 +150,7 @@ class ClipRunner:
         for l in range(self.L):
             k = f'l{l}.'
             _, h1, m1, r1 = K.layernorm_fwd(x, W.p(k + 'ln1.w'), W.p(k + 'ln1.b'), M, D, want_f32=False, want_bf16=True, eps=self.eps)
-            _, qkv, _ = K.linear_fwd(h1, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), M, 3 * D, D, want_bf16=True)
-            ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, T, T, D // H)
+            qkv, ctx = _qkv_attention(h1, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), B, H, T, D, None, NO_DROP, K.FUSED_ATTENTION_ENCODERS)
             x1, _, _ = K.linear_fwd(ctx, W.s(k + 'out_w'), W.p(k + 'out_b'), M, D, D, want_f32=True, residual=x)
             _, h2, m2, r2 = K.layernorm_fwd(x1, W.p(k + 'ln2.w'), W.p(k + 'ln2.b'), M, D, want_f32=False, want_bf16=True, eps=self.eps)
             _, g, a = K.linear_fwd(h2, W.s(k + 'fc1_w'), W.p(k + 'fc1_b'), M, I, D, want_bf16=True, want_pre=True, act=K.ACT_QUICK_GELU)
@@ -194,9 +223,7 @@ class RobertaRunner:
         for l in range(self.L):
             k = f'l{l}.'
             st = 8 * (l + 1)
-            _, qkv, _ = K.linear_fwd(xb, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), M, 3 * D, D, want_bf16=True)
-            ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, S, S, D // H, kpm,
-                                  Drop(pa, seed, st))
+            qkv, ctx = _qkv_attention(xb, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), B, H, S, D, kpm, Drop(pa, seed, st), K.FUSED_ATTENTION_ENCODERS)
             s1, _, _ = K.linear_fwd(ctx, W.s(k + 'ao_w'), W.p(k + 'ao_b'), M, D, D, want_f32=True, residual=x, drop=Drop(pd, seed, st + 1))
             x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p(k + 'ao_ln.w'), W.p(k + 'ao_ln.b'), M, D, want_bf16=True, eps=self.eps)
             _, g, a = K.linear_fwd(x1b, W.s(k + 'i_w'), W.p(k + 'i_b'), M, I, D, want_bf16=True, want_pre=True, act=K.ACT_GELU)
@@ -270,15 +297,12 @@ class CrossModalAttentionRunner:
         kvb = K.cast_bf16(key_value.reshape(Mv, D).contiguous().float())
         qm, km = _mask_u8(query_mask), _mask_u8(kv_mask)
         # --- self attention
-        _, qkv, _ = K.linear_fwd(xb, W.s('sa_in_w'), W.p('sa_in_b'), M, 3 * D, D, want_bf16=True)
-        ctx = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh, qm, Drop(pd, seed, 1))
+        qkv, ctx = _qkv_attention(xb, W.s('sa_in_w'), W.p('sa_in_b'), B, H, Sq, D, qm, Drop(pd, seed, 1), K.FUSED_ATTENTION_FUSION)
         s1, _, _ = K.linear_fwd(ctx, W.s('sa_out_w'), W.p('sa_out_b'), M, D, D, want_f32=True, residual=x, drop=Drop(pd, seed, 2))
         x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p('n1.w'), W.p('n1.b'), M, D, want_bf16=True, eps=self.eps)
         # --- cross attention: q from text, k/v from vision (rows D: of the packed in_proj)
         w_in, b_in = W.s('ca_in_w'), W.p('ca_in_b')
-        _, q2, _ = K.linear_fwd(x1b, w_in[:D], b_in[:D], M, D, D, want_bf16=True)
-        _, kv2, _ = K.linear_fwd(kvb, w_in[D:], b_in[D:], Mv, 2 * D, D, want_bf16=True)
-        ctx2 = K.attention_fwd(q2, kv2[:, :D], kv2[:, D:], D, 2 * D, 2 * D, B, H, Sq, Skv, Dh, km, Drop(pd, seed, 3))
+        q2, kv2, ctx2 = _q_kv_attention(x1b, kvb, w_in, b_in, B, H, Sq, Skv, D, km, Drop(pd, seed, 3))
         s2, _, _ = K.linear_fwd(ctx2, W.s('ca_out_w'), W.p('ca_out_b'), M, D, D, want_f32=True, residual=x1, drop=Drop(pd, seed, 4))
         x2, x2b, m2, r2 = K.layernorm_fwd(s2, W.p('n2.w'), W.p('n2.b'), M, D, want_bf16=True, eps=self.eps)
         # --- FFN: Linear, GELU, Dropout, Linear, Dropout
@@ -363,16 +387,12 @@ class CrossModalAttentionRunner:
         qm, km = _mask_u8(query_mask), _mask_u8(kv_mask)
         # --- self attention: one query (token 0) per sample over all text tokens
         w_sa, b_sa = W.s('sa_in_w'), W.p('sa_in_b')
-        _, q0, _ = K.linear_fwd(x0b, w_sa[:D], b_sa[:D], B, D, D, want_bf16=True)
-        _, kvs, _ = K.linear_fwd(xb, w_sa[D:], b_sa[D:], M, 2 * D, D, want_bf16=True)
-        ctx = K.attention_fwd(q0, kvs[:, :D], kvs[:, D:], D, 2 * D, 2 * D, B, H, 1, Sq, Dh, qm, Drop(pd, seed, 1))
+        q0, kvs, ctx = _q_kv_attention(x0b, xb, w_sa, b_sa, B, H, 1, Sq, D, qm, Drop(pd, seed, 1))
         s1, _, _ = K.linear_fwd(ctx, W.s('sa_out_w'), W.p('sa_out_b'), B, D, D, want_f32=True, residual=x0, drop=Drop(pd, seed, 2))
         x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p('n1.w'), W.p('n1.b'), B, D, want_bf16=True, eps=self.eps)
         # --- cross attention
         w_in, b_in = W.s('ca_in_w'), W.p('ca_in_b')
-        _, q2, _ = K.linear_fwd(x1b, w_in[:D], b_in[:D], B, D, D, want_bf16=True)
-        _, kv2, _ = K.linear_fwd(kvb, w_in[D:], b_in[D:], Mv, 2 * D, D, want_bf16=True)
-        ctx2 = K.attention_fwd(q2, kv2[:, :D], kv2[:, D:], D, 2 * D, 2 * D, B, H, 1, Skv, Dh, km, Drop(pd, seed, 3))
+        q2, kv2, ctx2 = _q_kv_attention(x1b, kvb, w_in, b_in, B, H, 1, Skv, D, km, Drop(pd, seed, 3))
         s2, _, _ = K.linear_fwd(ctx2, W.s('ca_out_w'), W.p('ca_out_b'), B, D, D, want_f32=True, residual=x1, drop=Drop(pd, seed, 4))
         x2, x2b, m2, r2 = K.layernorm_fwd(s2, W.p('n2.w'), W.p('n2.b'), B, D, want_bf16=True, eps=self.eps)
         # --- FFN

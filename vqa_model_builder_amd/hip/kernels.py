@@ -43,6 +43,7 @@ def L():
 
 _gd = _l.VqaGemmDesc()
 _ad = _l.VqaAttnDesc()
+_fd = _l.VqaFusedAttnDesc()
 
 
 class Drop:
@@ -255,6 +256,66 @@ def gather_rows(src, idx_i32, n, D, ld_src=None, want_f32=False, want_bf16=True)
     return dst, dstb
 
 
+# ---- row kernels of the expert runners (csrc/expert_ops.hip) --------------------------------------------------------
+
+def rows_mask_cast(dy, M, N, *, pre=None, act=ACT_NONE, drop: Drop = NO_DROP, colsum=None, ld=None):
+    """bf16(dy * act'(pre) * dropmask) [M, N] and, fused, its column sums ADDED into ``colsum`` (a zero-filled arena slot)."""
+    out = torch.empty((M, N), dtype=HALF(), device=dy.device)
+    _chk(L().vqa_rows_mask_cast(_p(dy), ld or N, _p(pre), act, _p(out), _p(colsum), M, N, drop.p, drop.seed, drop.stream, _stream()),
+         'vqa_rows_mask_cast')
+    return out
+
+
+def head_keep_fwd(v, T, R, H, Dh, drop: Drop = NO_DROP):
+    out = torch.empty((T * R, H * Dh), dtype=HALF(), device=v.device)
+    _chk(L().vqa_head_keep_fwd(_p(v), _p(out), T, R, H, Dh, drop.p, drop.seed, drop.stream, _stream()), 'vqa_head_keep_fwd')
+    return out
+
+
+def head_keep_bwd(dout, T, R, H, Dh, drop: Drop = NO_DROP):
+    dv = torch.empty((T, H * Dh), dtype=HALF(), device=dout.device)
+    _chk(L().vqa_head_keep_bwd(_p(dout), _p(dv), T, R, H, Dh, drop.p, drop.seed, drop.stream, _stream()), 'vqa_head_keep_bwd')
+    return dv
+
+
+def repeat_rows(src, out_rows, D, R, mode, alpha=1.0, want_f32=True, want_bf16=False):
+    dst = torch.empty((out_rows, D), dtype=F32, device=src.device) if want_f32 else None
+    dstb = torch.empty((out_rows, D), dtype=HALF(), device=src.device) if want_bf16 else None
+    _chk(L().vqa_repeat_rows_f32(_p(src), _p(dst), _p(dstb), out_rows, D, R, mode, alpha, _stream()), 'vqa_repeat_rows_f32')
+    return dst, dstb
+
+
+def rows_mean(x, R, T, D, out=None, out_bf16=None, ld_out=None):
+    _chk(L().vqa_rows_mean_f32(_p(x), R, _p(out), _p(out_bf16), ld_out or D, T, D, _stream()), 'vqa_rows_mean_f32')
+
+
+def take_stride(src_h16, n, stride, offset):
+    dst = torch.empty((n,), dtype=HALF(), device=src_h16.device)
+    _chk(L().vqa_take_stride_bf16(_p(src_h16), _p(dst), n, stride, offset, _stream()), 'vqa_take_stride_bf16')
+    return dst
+
+
+def scatter_stride(src_f32, dst_f32, n, stride, offset):
+    _chk(L().vqa_scatter_stride_f32(_p(src_f32), _p(dst_f32), n, stride, offset, _stream()), 'vqa_scatter_stride_f32')
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def moe_dense_combine_fwd(ys, w_all, T, E, D):
+    out = torch.empty((T, D), dtype=F32, device=w_all.device)
+    _chk(L().vqa_moe_dense_combine_fwd(_ptr_array(ys), _p(w_all), _p(out), T, E, D, _stream()), 'vqa_moe_dense_combine_fwd')
+    return out
+
+
+def moe_dense_combine_bwd(dout, ys, w_all, T, E, D):
+    dys = [torch.empty((T, D), dtype=F32, device=dout.device) for _ in range(E)]
+    dw = torch.empty((E, T), dtype=F32, device=dout.device)
+    _chk(L().vqa_moe_dense_combine_bwd(_p(dout), _ptr_array(ys), _p(w_all), _ptr_array(dys), _p(dw), T, E, D, _stream()), 'vqa_moe_dense_combine_bwd')
+    return dys, dw
+
+
 # ---- LayerNorm ------------------------------------------------------------------------------------------------
 
 def layernorm_fwd(x, gamma, beta, rows, cols, *, add=None, want_f32=True, want_bf16=False, eps=1e-5, drop: Drop = NO_DROP):
@@ -357,6 +418,34 @@ def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, ld
     d.ws = _p(ws)
     _chk(L().vqa_attention_bwd(C.byref(d), _stream()), 'vqa_attention_bwd')
     d.dq_colsum = d.dk_colsum = d.dv_colsum = d.ws = None
+
+
+FUSED_INPROJ_ATTENTION = True      # master switch of the fused in-projection + attention launch (csrc/fused_attn.h)
+FUSED_ATTENTION_FUSION = True      # ... in the CrossModalAttention fusion block (self- and cross-attention, both layer forms)
+FUSED_ATTENTION_ENCODERS = True    # ... in the CLIP ViT / PhoBERT layer stacks
+
+
+def fused_attention_covers(D, H, Sq, Skv):
+    return FUSED_INPROJ_ATTENTION and D % 64 == 0 and D % H == 0 and D // H in (64, 96) and 1 <= Sq <= 64 and 1 <= Skv <= 64
+
+
+def fused_inproj_attention_fwd(xq, xkv, w_in, b_in, B, H, Sq, Skv, D, mask_u8=None, drop: Drop = NO_DROP, *, q=None, k=None, v=None,
+                               ldq=None, ldk=None, ldv=None, ldxq=None, ldxkv=None, out=None):
+    """attention(xq Wq^T + bq, xkv Wk^T + bk, xkv Wv^T + bv) per (sample, head) in ONE launch (csrc/fused_attn.h); ``q`` / ``k`` /
+    ``v``: optional bf16 destinations of the projections (what backward reads).  Returns the bf16 context [B*Sq, D]."""
+    if out is None:
+        out = torch.empty((B * Sq, D), dtype=HALF(), device=xq.device)
+    d = _fd
+    d.xq, d.ldxq, d.xkv, d.ldxkv = _p(xq), ldxq or D, _p(xkv), ldxkv or D
+    d.w_in, d.ldw, d.b_in = _p(w_in), D, _p(b_in)
+    d.q, d.k, d.v = _p(q), _p(k), _p(v)
+    d.ldq, d.ldk, d.ldv = ldq or D, ldk or D, ldv or D
+    d.o, d.ldo = _p(out), D
+    d.B, d.H, d.Sq, d.Skv, d.D = B, H, Sq, Skv, D
+    d.key_padding_mask, d.scale = _p(mask_u8), 0.0
+    d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
+    _chk(L().vqa_fused_inproj_attention_fwd(C.byref(d), _stream()), 'vqa_fused_inproj_attention_fwd')
+    return out
 
 
 # ---- CLIP / RoBERTa front ends ------------------------------------------------------------------------------------

@@ -29,6 +29,13 @@ class VqaAttnDesc(C.Structure):
                 ('lddq', i32), ('lddk', i32), ('lddv', i32), ('dq_colsum', vp), ('dk_colsum', vp), ('dv_colsum', vp), ('ws', vp)]
 
 
+class VqaFusedAttnDesc(C.Structure):
+    _fields_ = [('xq', vp), ('ldxq', i32), ('xkv', vp), ('ldxkv', i32), ('w_in', vp), ('ldw', i32), ('b_in', vp),
+                ('q', vp), ('k', vp), ('v', vp), ('ldq', i32), ('ldk', i32), ('ldv', i32), ('o', vp), ('ldo', i32),
+                ('B', i32), ('H', i32), ('Sq', i32), ('Skv', i32), ('D', i32), ('key_padding_mask', vp),
+                ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32)]
+
+
 class VqaGemmGroupItem(C.Structure):
     _fields_ = [('a', vp), ('b', vp), ('c_f32', vp), ('M', i32), ('N', i32), ('K', i32), ('lda', i32), ('ldb', i32), ('ldc', i32)]
 
@@ -69,6 +76,7 @@ SIGNATURES = {
     'vqa_layernorm_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, u64, u32, i32, vp]),
     'vqa_set_attention_mfma': (None, [i32]),
     'vqa_attention_fwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
+    'vqa_fused_inproj_attention_fwd': (i32, [C.POINTER(VqaFusedAttnDesc), vp]),
     'vqa_attention_bwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
     'vqa_roberta_embed_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'vqa_roberta_embed_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -83,6 +91,15 @@ SIGNATURES = {
     'vqa_moe_scatter_add': (i32, [vp, vp, vp, vp, i32, i32, vp]),
     'vqa_moe_combine_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     'vqa_moe_route_weight_grad': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_moe_dense_combine_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_moe_dense_combine_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_rows_mask_cast': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, u64, u32, vp]),
+    'vqa_head_keep_fwd': (i32, [vp, vp, i32, i32, i32, i32, f32, u64, u32, vp]),
+    'vqa_head_keep_bwd': (i32, [vp, vp, i32, i32, i32, i32, f32, u64, u32, vp]),
+    'vqa_repeat_rows_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    'vqa_rows_mean_f32': (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
+    'vqa_take_stride_bf16': (i32, [vp, vp, sz, i32, i32, vp]),
+    'vqa_scatter_stride_f32': (i32, [vp, vp, sz, i32, i32, vp]),
     'vqa_randn_f32': (i32, [vp, u64, u64, u32, vp]),
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
     'vqa_gemm_bf16_grouped': (i32, [vp, i32, i32, i32, vp]),

@@ -14,8 +14,16 @@ import torch
 import torch.nn as nn
 
 from ...hip import ops
+from ...hip.expert_blocks import SegmentationExpertRunner, TextExpertRunner, VisionExpertRunner
 from ...hip.kernels import ACT_GELU, ACT_NONE, ACT_RELU, Drop
+from ...hip.kernels import skip_weight_grads as K_skip
+from ..meta_arch.backbones import _BlockFn, _Weights, _flatten_param_keys, _split_grads
 from ..meta_arch.vqa_model import _MHAParams
+
+# One token per row (the shape the VQA model feeds the MoE, vqa_model.py:674): each expert runs as ONE autograd node with a
+# hand-scheduled forward / backward (hip/expert_blocks.py).  False: the op-by-op chains below (any S, masks, extra inputs) --
+# what the runners are tested against.
+EXPERT_RUNNERS = True
 
 
 def _drop(p, training, stream):
@@ -36,6 +44,42 @@ class BaseExpert(ABC, nn.Module):
     @abstractmethod
     def forward(self, x, mask=None, **kwargs):
         pass
+
+    # ---- runner plumbing (subclasses that have a runner fill self._W / self._runner in _init_runner) -------------------
+    _runner = None
+
+    def _bind(self, pairs, shadows):
+        """``pairs``: key -> parameter handed to the runner; ``shadows``: keys whose parameter is a GEMM operand (bf16 copy)."""
+        W = _Weights()
+        for key, prm in pairs.items():
+            W.params[key] = prm
+        for key in shadows:
+            prm = pairs[key]
+            W.shadows.add(key, prm, (prm.shape[0], prm.numel() // prm.shape[0]))
+        self._W = W
+        self._flat = _flatten_param_keys(W.params)
+        return W
+
+    def _use_runner(self, x, mask, extra):
+        return (EXPERT_RUNNERS and self._runner is not None and x.dim() == 3 and x.shape[1] == 1 and mask is None
+                and all(v is None for v in extra))
+
+    def _run(self, x):
+        T, _, D = x.shape
+        out = _BlockFn.apply(self, 1, x.reshape(T, D), *[p for _, p in self._flat])
+        return out.view(T, 1, self.output_dim)
+
+    def _hip_forward(self, x2):
+        self._W.shadows.refresh(x2.device)
+        return self._runner.forward(x2, self.training)
+
+    def _hip_backward(self, saved, dout, needs):
+        if not any(p.requires_grad for _, p in self._flat):
+            with K_skip(True):                 # frozen expert: dX only
+                G, dx = self._runner.backward(saved, dout, need_dx=needs[0])
+        else:
+            G, dx = self._runner.backward(saved, dout, need_dx=needs[0])
+        return [dx], _split_grads(self._flat, G)
 
     def update_usage_stats(self, num_tokens: int):
         self.usage_count += 1
@@ -118,8 +162,20 @@ class VisionExpert(BaseExpert):
                                        nn.Linear(hidden_dim, hidden_dim), nn.Dropout(dropout))
         self.output_proj = nn.Linear(hidden_dim, output_dim)
         self.output_norm = nn.LayerNorm(output_dim)
+        P = {'in_w': self.input_proj.weight, 'in_b': self.input_proj.bias}
+        sh = ['in_w', 't0_w', 't3_w', 'out_w']
+        if use_spatial_attention:
+            a = self.spatial_attention
+            P.update({'sa_in_wz': a.in_proj_weight, 'sa_in_bz': a.in_proj_bias, 'sa_out_w': a.out_proj.weight, 'sa_out_b': a.out_proj.bias,
+                      'sn.w': self.spatial_norm.weight, 'sn.b': self.spatial_norm.bias})
+            sh += ['sa_in_wz', 'sa_out_w']
+        P.update({'t0_w': self.transform[0].weight, 't0_b': self.transform[0].bias, 't3_w': self.transform[3].weight, 't3_b': self.transform[3].bias,
+                  'out_w': self.output_proj.weight, 'out_b': self.output_proj.bias, 'on.w': self.output_norm.weight, 'on.b': self.output_norm.bias})
+        self._runner = VisionExpertRunner(self._bind(P, sh), input_dim, hidden_dim, output_dim, num_heads, dropout, attention=use_spatial_attention)
 
     def forward(self, x, mask=None, spatial_positions=None, **kwargs):
+        if self._use_runner(x, mask, (spatial_positions,)):
+            return self._run(x)
         h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
         if spatial_positions is not None:
             h = ops.add(h, spatial_positions)
@@ -147,8 +203,21 @@ class TextExpert(BaseExpert):
         self.ffn_norm = nn.LayerNorm(hidden_dim)
         self.output_proj = nn.Linear(hidden_dim, output_dim)
         self.output_norm = nn.LayerNorm(output_dim)
+        P = {'in_w': self.input_proj.weight, 'in_b': self.input_proj.bias}
+        sh = ['in_w', 'f0_w', 'f3_w', 'out_w']
+        if use_self_attention:
+            a = self.self_attention
+            P.update({'sa_in_wz': a.in_proj_weight, 'sa_in_bz': a.in_proj_bias, 'sa_out_w': a.out_proj.weight, 'sa_out_b': a.out_proj.bias,
+                      'an.w': self.attention_norm.weight, 'an.b': self.attention_norm.bias})
+            sh += ['sa_in_wz', 'sa_out_w']
+        P.update({'f0_w': self.ffn[0].weight, 'f0_b': self.ffn[0].bias, 'f3_w': self.ffn[3].weight, 'f3_b': self.ffn[3].bias,
+                  'fn.w': self.ffn_norm.weight, 'fn.b': self.ffn_norm.bias,
+                  'out_w': self.output_proj.weight, 'out_b': self.output_proj.bias, 'on.w': self.output_norm.weight, 'on.b': self.output_norm.bias})
+        self._runner = TextExpertRunner(self._bind(P, sh), input_dim, hidden_dim, output_dim, num_heads, dropout, attention=use_self_attention, stream0=121)
 
     def forward(self, x, mask=None, **kwargs):
+        if self._use_runner(x, mask, ()):
+            return self._run(x)
         h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
         if self.use_self_attention:
             kpm = ~mask.bool() if mask is not None else None
@@ -180,8 +249,16 @@ class MultimodalExpert(BaseExpert):
         self.transform_norm = nn.LayerNorm(hidden_dim)
         self.output_proj = nn.Linear(hidden_dim, output_dim)
         self.output_norm = nn.LayerNorm(output_dim)
+        P = {'in_w': self.input_proj.weight, 'in_b': self.input_proj.bias,
+             'f0_w': self.transform[0].weight, 'f0_b': self.transform[0].bias, 'f3_w': self.transform[3].weight, 'f3_b': self.transform[3].bias,
+             'fn.w': self.transform_norm.weight, 'fn.b': self.transform_norm.bias,
+             'out_w': self.output_proj.weight, 'out_b': self.output_proj.bias, 'on.w': self.output_norm.weight, 'on.b': self.output_norm.bias}
+        self._runner = TextExpertRunner(self._bind(P, ['in_w', 'f0_w', 'f3_w', 'out_w']), input_dim, hidden_dim, output_dim, num_heads, dropout,
+                                        attention=False, stream0=131)
 
     def forward(self, x, mask=None, context=None, context_mask=None, **kwargs):
+        if self._use_runner(x, None, (context,)):          # without context the mask is never read (reference expert_types.py:414-445)
+            return self._run(x)
         h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
         if self.use_cross_attention and context is not None:
             raise NotImplementedError('MultimodalExpert(context=...) is unreachable from MOELayer in the reference '
@@ -268,6 +345,7 @@ def _conv1d_k3(conv: nn.Conv1d, x, act):
 
 class SegmentationExpert(BaseExpert):
     """Reference specialized_experts.py:15-173."""
+    long_chain = True
 
     def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_mask_tokens=4,
                  use_pretrained_sam=False, sam_model_type='vit_b'):
@@ -283,8 +361,26 @@ class SegmentationExpert(BaseExpert):
 
         self.output_proj = nn.Linear(hidden_dim, output_dim)
         self.output_norm = nn.LayerNorm(output_dim)
+        P = {'mask_tokens': self.mask_tokens, 'in_w': self.input_proj.weight, 'in_b': self.input_proj.bias}
+        sh = ['in_w', 'c0_k', 'c2_k', 'm0_w', 'm3_w', 'out_w']
+        for l, layer in enumerate(self.mask_transformer.layers):
+            k = f'd{l}.'
+            sa, ca = layer.self_attn, layer.multihead_attn
+            P.update({k + 'sa_in_w': sa.in_proj_weight, k + 'sa_in_b': sa.in_proj_bias, k + 'sa_out_w': sa.out_proj.weight, k + 'sa_out_b': sa.out_proj.bias,
+                      k + 'ca_in_wz': ca.in_proj_weight, k + 'ca_in_bz': ca.in_proj_bias, k + 'ca_out_w': ca.out_proj.weight, k + 'ca_out_b': ca.out_proj.bias,
+                      k + 'l1_w': layer.linear1.weight, k + 'l1_b': layer.linear1.bias, k + 'l2_w': layer.linear2.weight, k + 'l2_b': layer.linear2.bias})
+            for i, n in enumerate((layer.norm1, layer.norm2, layer.norm3), 1):
+                P[k + f'n{i}.w'], P[k + f'n{i}.b'] = n.weight, n.bias
+            sh += [k + 'sa_in_w', k + 'sa_out_w', k + 'ca_in_wz', k + 'ca_out_w', k + 'l1_w', k + 'l2_w']
+        bc, m = self.boundary_conv, self.spatial_mlp
+        P.update({'c0_k': bc[0].weight, 'c0_b': bc[0].bias, 'c2_k': bc[2].weight, 'c2_b': bc[2].bias,
+                  'm0_w': m[0].weight, 'm0_b': m[0].bias, 'm3_w': m[3].weight, 'm3_b': m[3].bias,
+                  'out_w': self.output_proj.weight, 'out_b': self.output_proj.bias, 'on.w': self.output_norm.weight, 'on.b': self.output_norm.bias})
+        self._runner = SegmentationExpertRunner(self._bind(P, sh), input_dim, hidden_dim, output_dim, 8, dropout, num_mask_tokens, 2)
 
     def forward(self, x, mask=None, image_features=None, **kwargs):
+        if self._use_runner(x, None, ()):                  # mask / image_features are never read by the reference forward (:119-173)
+            return self._run(x)
         B, S, _ = x.shape
         h = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
         mask_feat = self.mask_transformer(self.mask_tokens.expand(B, -1, -1), h)             # [B,M,H]
@@ -301,6 +397,7 @@ class SegmentationExpert(BaseExpert):
 
 class ObjectDetectionExpert(BaseExpert):
     """Reference specialized_experts.py:176-308 (reachable from 8 experts up)."""
+    long_chain = True
 
     def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1, num_queries=100,
                  num_decoder_layers=3):

@@ -86,6 +86,30 @@ class _CombineFn(torch.autograd.Function):
         return (dweights.view(wshape), None, None, None, None, None, None) + tuple(dys)
 
 
+class _DenseCombineFn(torch.autograd.Function):
+    """Dense dispatch: out[t] = sum_e w_all[e,t] * y_e[t] over ALL experts in one launch (w_all is 0 where an expert was not chosen:
+    the reference's own formulation, moe_layer.py:151-168); backward in one launch + the routing-weight gather."""
+
+    @staticmethod
+    def forward(ctx, weights, indices, w_all, T, D, *ys):
+        shapes = [y.shape for y in ys]
+        ys = [y.reshape(T, D).contiguous().float() for y in ys]
+        out = K.moe_dense_combine_fwd(ys, w_all, T, len(ys), D)
+        ctx.save_for_backward(indices, w_all, *ys)
+        ctx.meta = (T, D, weights.shape, shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        indices, w_all, *ys = ctx.saved_tensors
+        T, D, wshape, shapes = ctx.meta
+        E, Kk = len(ys), indices.shape[-1]
+        dys, dw_all = K.moe_dense_combine_bwd(dout.contiguous().float(), ys, w_all, T, E, D)
+        dweights = torch.empty((T, Kk), dtype=torch.float32, device=dout.device)
+        K._chk(K.L().vqa_moe_route_weight_grad(dw_all.data_ptr(), indices.data_ptr(), dweights.data_ptr(), T, E, Kk, K._stream()), 'vqa_moe_route_weight_grad')
+        return (dweights.view(wshape), None, None, None, None) + tuple(dy.view(sh) for dy, sh in zip(dys, shapes))
+
+
 class MOELayer(nn.Module):
     """Reference moe_layer.py:29-196."""
 
@@ -117,6 +141,7 @@ class MOELayer(nn.Module):
     # instead of none, and its parameters carry `_vqa_active` (device word = its routed-token count) so that FusedAdamW
     # leaves them alone exactly as it skips a grad-is-None parameter.
     dense_dispatch = False
+    parallel_branches = 0          # dense dispatch: experts on side streams (0 off, 1 specialised experts, 2 every expert; profiles/r02/moe.md)
 
     def enable_dense_dispatch(self, on: bool = True):
         self.dense_dispatch = on
@@ -130,20 +155,46 @@ class MOELayer(nn.Module):
 
     def _forward_dense(self, x, mask, w2, i2, B, S, D, kwargs):
         T, E = B * S, len(self.experts)
-        valid = i2 >= 0                                           # -1 routes nowhere (ablation harness contract)
-        idx = i2.clamp(min=0)
-        w_all = torch.zeros((T, E), dtype=torch.float32, device=x.device).scatter_add(1, idx, w2 * valid)
-        with torch.no_grad():
-            self._active.copy_(torch.zeros((E,), dtype=torch.float32, device=x.device).scatter_add_(
-                0, idx.reshape(-1), valid.reshape(-1).float()))
-        out = None
-        for e, expert in enumerate(self.experts):
+        dev = x.device
+        w_all = torch.empty((E, T), dtype=torch.float32, device=dev)       # w_all[e,t] = sum_k w2[t,k] * (i2[t,k] == e); -1 routes nowhere
+        lists = torch.empty((E, T), dtype=torch.int32, device=dev)
+        counts = torch.empty((E,), dtype=torch.int32, device=dev)
+        K._chk(K.L().vqa_moe_expert_tokens(w2.detach().data_ptr(), i2.data_ptr(), T, w2.shape[-1], E, w_all.data_ptr(), lists.data_ptr(),
+                                           counts.data_ptr(), K._stream()), 'vqa_moe_expert_tokens')
+        self._active.copy_(counts)                                          # routed-token counts: FusedAdamW skips an expert nobody chose
+        def run(expert):
             if S == 1 or expert.token_local:
-                ye = expert(x.reshape(T, 1, D), **kwargs)
-            else:
-                ye = expert(x, mask=mask, **kwargs)
-            ye = ye.reshape(T, self.output_dim) * w_all[:, e:e + 1]
-            out = ye if out is None else out + ye
+                return expert(x.reshape(T, 1, D), **kwargs)
+            return expert(x, mask=mask, **kwargs)
+        # parallel_branches 1: the specialised experts (a 2-3 layer decoder: ~4x the dependent launches of the others) on a side HIP
+        # stream, the short experts on this one; 2: every expert but the first on a stream of its own.  Chains of latency-floor
+        # launches side by side; each expert's backward follows it to its stream.
+        mode = int(self.parallel_branches)
+        side_ids = [e for e, ex in enumerate(self.experts) if (getattr(ex, 'long_chain', False) if mode == 1 else e > 0)] if mode else []
+        if side_ids and len(side_ids) < E:
+            main = torch.cuda.current_stream()
+            if getattr(self, '_side_streams', None) is None:
+                self._side_streams = {}
+            ys = [None] * E
+            for j, e in enumerate(side_ids):
+                key = 0 if mode == 1 else j
+                side = self._side_streams.get(key)
+                if side is None:
+                    side = self._side_streams[key] = torch.cuda.Stream()
+                if mode != 1 or j == 0:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ys[e] = run(self.experts[e])
+            for e, expert in enumerate(self.experts):
+                if ys[e] is None:
+                    ys[e] = run(expert)
+            for side in self._side_streams.values():
+                main.wait_stream(side)
+            for e in side_ids:
+                ys[e].record_stream(main)
+        else:
+            ys = [run(expert) for expert in self.experts]
+        out = _DenseCombineFn.apply(w2, i2, w_all, T, self.output_dim, *ys)
         out = ops.layer_norm(out, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
         return out.view(B, S, self.output_dim)
 
