@@ -280,7 +280,9 @@ def main():
                     help="16-bit type of the GEMM / attention operands: bf16 (default) or fp16 (+ dynamic loss scale), the reference loop's autocast dtype")
     ap.add_argument('--no-second-workload', action='store_true',
                     help='skip the MoE config (BASELINE configs[2]) that is otherwise timed too and reported as the "moe_config" object of the line')
-    ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='wire format of the data-parallel gradient exchange')
+    ap.add_argument('--grad-dtype', default=None, choices=['fp32', 'bf16'],
+                    help='wire format of the data-parallel gradient exchange (default: bf16 buckets when N > 1 -- summed in bf16 on the wire, applied to fp32 '
+                         'master weights by the fp32 AdamW; fp32: what torch DDP sends)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-ws', type=int, default=None, help='diagnostics: vqa_set_gemm_ws mode (0 = legacy tiles only, 1 = auto)')
@@ -330,6 +332,8 @@ def main():
     if args.expert_runners is not None:
         from vqa_model_builder_amd.modeling.moe import experts as _E
         _E.EXPERT_RUNNERS = bool(args.expert_runners)
+    if args.grad_dtype is None:
+        args.grad_dtype = 'bf16' if world > 1 else 'fp32'
     main_res = run_workload(args.workload, args, device, world, rank, dist, want_roofline=not args.no_roofline)
     moe_res = None
     if not args.no_second_workload and args.workload != 'cfg3_mcan_moe4':
@@ -385,15 +389,24 @@ def main():
             seg = run_workload(args.workload, args, device, world, rank, dist, want_roofline=False)
             args.force_segmented = False
             BUS = 300e9                           # assumed all-reduce bus bandwidth of an 8-GPU xGMI node (7 links x ~153 GB/s per GPU, ~30 % of it)
-            sb = seg.get('segment_bytes', {})
-            last = sb.get('V', 0)
-            t_last = 2 * (7 / 8) * last / BUS * 1e3
-            dp_model = {'segmented_step_ms_1gpu': seg['ms_per_step'], 'segment_bytes': sb, 'assumed_bus_GBps': BUS / 1e9,
-                        'exposed_allreduce_ms_8gpu_model': round(t_last, 3),
-                        'predicted_8gpu_ms_per_step': round(seg['ms_per_step'] + t_last, 3),
-                        'predicted_8gpu_scaling': round(8 * main_res['ms_per_step'] / (seg['ms_per_step'] + t_last), 2),
-                        'note': 'compute = measured 5-graph step on one GPU (no exchange); + modelled ring time of the LAST block (vision arena): the other '
-                                'blocks travel beside the next block\'s backward; xGMI bus bandwidth is an assumption, not a measurement'}
+            sb, sm = seg.get('segment_bytes', {}), seg.get('segment_ms', {})
+            total = seg['ms_per_step']
+            t_opt = max(0.0, total - sum(sm.get(k, 0.0) for k in 'FHTV'))
+
+            def predict(wire):
+                # one RCCL stream: a block's exchange starts when its graph has finished AND the previous exchange is through
+                ready, end = sm.get('F', 0.0), 0.0
+                for k in 'HTV':
+                    ready += sm.get(k, 0.0)
+                    end = max(ready, end) + 2 * (7 / 8) * sb.get(k, 0) * wire / BUS * 1e3
+                exposed = max(0.0, end - ready)
+                step = ready + exposed + t_opt
+                return {'exposed_allreduce_ms': round(exposed, 3), 'ms_per_step': round(step, 3), 'scaling_vs_1gpu': round(8 * main_res['ms_per_step'] / step, 2)}
+            dp_model = {'segmented_step_ms_1gpu': total, 'segment_ms_1gpu': sm, 'optimizer_ms': round(t_opt, 3), 'segment_bytes_fp32': sb,
+                        'assumed_bus_GBps': BUS / 1e9, 'predicted_8gpu_fp32_buckets': predict(1.0), 'predicted_8gpu_bf16_buckets': predict(0.5),
+                        'note': 'compute = the five graphs of the segmented step measured on one GPU (no exchange); exchange = ring all-reduce of each '
+                                'block behind one RCCL stream, started when the block\'s graph is done; the xGMI bus bandwidth is an ASSUMPTION, not '
+                                'a measurement -- the driver\'s N = 8 run is the measurement'}
         except Exception as e:                       # noqa: BLE001
             args.force_segmented = False
             dp_model = {'error': f'{type(e).__name__}: {e}'}
@@ -414,7 +427,7 @@ def main():
                        'global_batch': args.batch * world, 'image': '3x224x224', 'seq_len': 64,
                        'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
                        'launch': main_res['launch'], 'final_loss': main_res['final_loss'],
-                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'grad_dtype', 'exposed_comm_ms', 'segment_bytes') if k in main_res}},
+                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'grad_dtype', 'exposed_comm_ms', 'segment_bytes', 'segment_ms') if k in main_res}},
             'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res, 'dp_model': dp_model,
         }
         print(json.dumps(line), flush=True)

@@ -301,10 +301,15 @@ typedef struct VqaOptJob {
                               * The captured MoE step runs every expert on every token (no host read of the routing counts);
                               * an expert no token chose must still be left alone by the optimiser, as the reference's
                               * grad-is-None skip does -- its routed-token count is this word. */
+    const float* own_step;   /* optional device word: this job's OWN step count (number of updates it received, this one included)
+                              * for the two bias corrections -- torch keeps `step` per parameter, so an expert skipped in some
+                              * steps must not have its corrections aged by them.  Advanced by vqa_opt_advance_counts. */
 } VqaOptJob;
 /* chunks_dev: uint32 [nchunks][2] = {job index, first element}; every chunk covers vqa_opt_chunk_elems() elements of its
  * tensor (the last one of a tensor fewer): one workgroup per chunk keeps the chip streaming whatever the tensor sizes. */
 int vqa_opt_chunk_elems(void);
+/* steps[i] += 1 where active[i] > 0 (and, when norm2 is given, only if it is finite: a step skipped by the loss scaler counts for nobody) */
+int vqa_opt_advance_counts(float* steps, const float* active, int n, const float* norm2, vqa_stream_t s);
 int vqa_sumsq_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int nchunks, float* norm2, vqa_stream_t s);
 /* hyper_dev (optional): device floats {lr, step}; when given they override lr and the two bias corrections (computed from
  * step on the device), so a captured HIP graph of the optimiser step follows the schedule and the step count. */

@@ -35,4 +35,4 @@ for tag in ('pmc_fetch', 'pmc_write', 'pmc_mfma'):
         w = csv.writer(fo); w.writerow(['kernel', 'counter', 'value', 'grid', 'workgroup']); w.writerows(rows)
     print(tag, len(rows), 'rows')
 PY
-tail -2 $out/graph.log; tail -2 $out/cfg3.log
+for k in graph eager cfg3; do grep "^{" $out/$k.log | tail -1 > $R/profiles/$rnd/${k}_bench_line.json; cp $out/${k}_kernel_stats.csv $R/profiles/$rnd/; done; cp $out/pmc_*_gemm_rows.csv $R/profiles/$rnd/

@@ -162,6 +162,52 @@ def test_fused_adamw_skips_parameters_of_an_expert_without_tokens():
     assert not torch.equal(a.detach(), a0) and torch.equal(b.detach(), b1)
 
 
+def test_fused_adamw_counts_an_experts_steps_on_the_device_like_torch_counts_them_per_parameter():
+    """torch.optim.AdamW keeps `step` per parameter: a parameter without a gradient in a step (an expert no token chose) is skipped
+    AND its bias corrections do not age.  Under dense dispatch the skip is a device word (`_vqa_active`); the expert's own update
+    count is one too (`_vqa_step`, advanced by vqa_opt_advance_counts), eagerly and under a replayed graph."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    pattern = [1, 0, 1, 1, 0, 0, 1]
+    for graphed in (False, True):
+        torch.manual_seed(3)
+        a = torch.nn.Parameter(torch.randn(70, 9, device='cuda'))
+        b = torch.nn.Parameter(torch.randn(33, device='cuda'))
+        ra, rb = torch.nn.Parameter(a.detach().clone()), torch.nn.Parameter(b.detach().clone())
+        act, steps = torch.ones(1, device='cuda'), torch.zeros(1, device='cuda')
+        a._vqa_active, a._vqa_step, a._vqa_counts = act[0:1], steps[0:1], (act, steps, 0)
+        opt = FusedAdamW([a, b], lr=1e-2, weight_decay=0.1, max_grad_norm=None)
+        ref = torch.optim.AdamW([ra, rb], lr=1e-2, weight_decay=0.1)
+        ga, gb = torch.randn(len(pattern), 70, 9, device='cuda'), torch.randn(len(pattern), 33, device='cuda')
+        a.grad, b.grad = torch.zeros_like(a), torch.zeros_like(b)
+        g = None
+        for i, on in enumerate(pattern):
+            act.fill_(float(on))
+            a.grad.copy_(ga[i] * on); b.grad.copy_(gb[i])
+            ra.grad, rb.grad = (ga[i].clone() if on else None), gb[i].clone()
+            ref.step()
+            if not graphed or i < 2:
+                opt.step()
+                if graphed and i == 1:
+                    opt.make_capturable('cuda')
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        with torch.cuda.graph(g, stream=s):
+                            opt.step()
+                    torch.cuda.synchronize()
+                    # the capture pass applied nothing
+            else:
+                g.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(a.detach(), ra.detach(), atol=2e-6, rtol=1e-5), (graphed, float((a - ra).abs().max()))
+        assert torch.allclose(b.detach(), rb.detach(), atol=2e-6, rtol=1e-5), graphed
+        assert int(steps.item()) == sum(pattern)
+        opt.sync_step_counts()
+        if graphed:
+            assert int(opt.state[a]['step']) == sum(pattern) and int(opt.state[b]['step']) == len(pattern)
+
+
 def test_moe_model_trains_under_a_replayed_graph():
     from vqa_model_builder_amd.graph import GraphedTrainStep
     from vqa_model_builder_amd.hip import blocks
@@ -172,13 +218,13 @@ def test_moe_model_trains_under_a_replayed_graph():
         gs = GraphedTrainStep(model, opt, batch, warmup=2)
         got = [gs(batch).item() for _ in range(4)]
         assert ref[0] - ref[-1] > 0.02, ref
-        # Steep tiny-model trajectory (loss 4.3 -> 0.6 in six steps, 3 tokens over 4 experts).  Two things separate the runs, both by
-        # design: (1) an expert without tokens in a step is skipped by both, but the captured optimiser keeps ONE device-side step
-        # count per group where torch keeps one per parameter, so such an expert's next update has a different bias correction
-        # (deterministic, 1.5 % at the third step here; at 32 tokens per step every expert is routed to practically always);
-        # (2) fp32 atomics reorder the bias-gradient sums, and the trajectory forks into one of two branches a few steps later
-        # (measured on MI355X, eager and graphed alike, whatever the stream layout: last losses 0.877 / 0.623 or 0.937 / 0.645
-        # against 0.857 / 0.606 for the eager sparse step -- scratch/dbg_moe_graph.py).
+        # Steep tiny-model trajectory (loss 4.3 -> 0.6 in six steps, 3 tokens over 4 experts: most steps leave an expert without a
+        # token).  Both runs skip such an expert AND count its updates separately (eager: torch's per-parameter `step`; captured:
+        # the device-side per-expert count, vqa_opt_advance_counts) -- with one shared count the trajectories drifted 1.5 % apart by
+        # the third step; now (MI355X): 1.9236 / 1.2484 / 0.8609 / 0.6088 against 1.9200 / 1.2494 / 0.8572 / 0.6064.  What remains is
+        # run-to-run: fp32 atomics reorder the bias-gradient sums and this trajectory forks a few steps in, for the EAGER reference
+        # as well (second measured reference: 1.9273 / 1.2567 / 0.9124 / 0.6245) -- hence 12 % on the late steps, 1 % on the first.
+        assert abs(ref[2] - got[0]) <= 1e-2 * ref[2], (ref, got)
         for x, y in zip(ref[2:], got):
             assert abs(x - y) <= 0.12 * max(1.0, abs(x)), (ref, got)
         assert got[0] - got[-1] > 0.5 * (ref[2] - ref[-1]), (ref, got)        # and it trains at the same pace

@@ -263,6 +263,11 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
     }
     const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
     if (j.active && j.active[0] == 0.f) return;          // expert no token was routed to: skipped like a grad-is-None parameter
+    if (j.own_step) {                                    // ... and its bias corrections follow the number of updates IT received (torch keeps
+        const float t = fmaxf(j.own_step[0], 1.f);       // `step` per parameter: a skipped step does not age the moments' correction)
+        bc1 = 1.f - powf(beta1, t);
+        bc2 = 1.f - powf(beta2, t);
+    }
     const uint64_t beg = chunks[2 * blockIdx.x + 1];
     const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
     // prescale: the gradients in memory are SUMS over `1/prescale` data-parallel ranks; their mean is never materialised
@@ -313,6 +318,11 @@ __global__ void amp_update_kernel(float* __restrict__ amp, const float* __restri
 __global__ void opt_advance_kernel(float* __restrict__ hyper, const float* __restrict__ norm2) {
     if (!norm2 || isfinite(norm2[0])) hyper[1] += 1.f;
 }
+// per-expert step counts: an expert's count advances in the steps in which a token was routed to it
+__global__ void opt_advance_counts_kernel(float* __restrict__ steps, const float* __restrict__ active, int n, const float* __restrict__ norm2) {
+    const int i = threadIdx.x;
+    if (i < n && active[i] > 0.f && (!norm2 || isfinite(norm2[0]))) steps[i] += 1.f;
+}
 
 // ---- nn.Bilinear as a GEMM: z[b, i*D2 + j] = x1[b,i] * x2[b,j] (bf16 operand of y = z W^T), and the contraction of dz back ----
 __global__ void outer_bf16_kernel(const float* __restrict__ x1, const float* __restrict__ x2, h16_t* __restrict__ z, int B, int D1, int D2) {
@@ -355,7 +365,7 @@ __global__ void outer_bwd_x2_kernel(const float* __restrict__ dz, const float* _
 
 extern "C" {
 
-int vqa_abi_version(void) { return 2; }
+int vqa_abi_version(void) { return 3; }
 int vqa_half_kind(void) { return VQA_HALF_KIND; }
 int vqa_outer_bf16(const float* x1, const float* x2, void* z_bf16, int B, int D1, int D2, vqa_stream_t s) {
     if (!x1 || !x2 || !z_bf16 || B <= 0 || D1 <= 0 || D2 <= 0 || D2 % 4) return VQA_ERR_ARG;
@@ -391,6 +401,11 @@ int vqa_adamw_multi(const VqaOptJob* jobs_dev, const uint32_t* chunks_dev, int n
 int vqa_amp_update(float* amp_dev, const float* norm2, float growth_factor, float backoff_factor, int growth_interval, vqa_stream_t s) {
     if (!amp_dev || !norm2 || growth_interval < 1) return VQA_ERR_ARG;
     hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, amp_dev, norm2, growth_factor, backoff_factor, growth_interval);
+    return (int)hipGetLastError();
+}
+int vqa_opt_advance_counts(float* steps, const float* active, int n, const float* norm2, vqa_stream_t s) {
+    if (!steps || !active || n <= 0 || n > 1024) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(opt_advance_counts_kernel, dim3(1), dim3((n + 63) / 64 * 64), 0, (hipStream_t)s, steps, active, n, norm2);
     return (int)hipGetLastError();
 }
 int vqa_opt_advance(float* hyper_dev, const float* norm2, vqa_stream_t s) {

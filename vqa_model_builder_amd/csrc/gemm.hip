@@ -1070,12 +1070,16 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         //   everything else with >= 256 rows       -> 64x64 tiles, 3-stage ring (back-to-back microbenchmarks prefer 2 stages
         //                                             for short k / big grids; inside the step, beside the other encoder's
         //                                             launches, 3 stages everywhere measured 2 % faster end to end)
-        //   small M (< 256)                        -> 64x64 register-staged double buffer
+        //   32 < M < 256 (the Segmentation expert's 4 mask tokens x 32 samples; k-contiguous A)
+        //                                          -> 32x32 tiles through a 3-stage ring, as for M <= 32: these launches stream a
+        //                                             2048 x 2048 .. 6144 weight past a handful of rows, and what they need is
+        //                                             workgroups (profiles/r02/gemm_mid_m.log: 128 x 2048 x 4096 40.5 -> 16.6 us,
+        //                                             dX 128 x 2048 x 6144 60.5 -> 24.4 us against the register-staged 64x64 kernel)
         cfg = 1; dma = false;
         if (d->a_kc && d->M >= 512 && d->N >= 1536) { cfg = 4; dma = true; stages = 2; }
         else if (d->M >= 256 && d->N >= 64) {
             cfg = 1; dma = true; stages = 3;
-        }
+        } else if (d->a_kc && d->N >= 64) { cfg = 7; dma = true; stages = 3; }
         if (g_force_cfg >= 0 && dma) { cfg = g_force_cfg; stages = g_force_stages; }     // diagnostics (vqa_set_gemm_force)
     }
     const int bm = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 32 : cfg == 3 ? 128 : cfg == 4 ? 128 : cfg == 6 ? 256 : cfg >= 7 ? 32 : 64;

@@ -73,6 +73,7 @@ class GraphedTrainStep:
             segmented = reducer is not None and getattr(reducer, 'world', 1) > 1 and can_segment
         self.segmented = bool(segmented and can_segment and reducer is not None)
         self._exposed_ms, self._comm_events, self._replays = [], None, 0
+        self._segment_marks = []
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -208,16 +209,30 @@ class GraphedTrainStep:
             return {}
         self._exposed_ms = [e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in self._exposed_ms]
         v = sorted(self._exposed_ms)
-        return {'exposed_comm_ms': round(v[len(v) // 2], 3), 'segment_bytes': self.reducer.segment_bytes()}
+        out = {'exposed_comm_ms': round(v[len(v) // 2], 3), 'segment_bytes': self.reducer.segment_bytes()}
+        if self._segment_marks:
+            # median GPU time of each graph of the step (F: encoders forward, H: fusion + head forward / backward, T / V: encoder backward)
+            seg = {}
+            for j, name in enumerate(('F', 'H', 'T', 'V')):
+                ts = sorted(m[j].elapsed_time(m[j + 1]) for m in self._segment_marks)
+                seg[name] = round(ts[len(ts) // 2], 3)
+            out['segment_ms'] = seg
+        return out
 
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         if batch is not None:
             for k, v in batch.items():
                 self.static[k].copy_(v, non_blocking=True)
+        timed = self.segmented and len(self._exposed_ms) < 512
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        if timed:
+            marks[0].record()
         self.g_main.replay()
         if self.segmented:
             red = self.reducer
-            for name in ('H', 'T', 'V'):
+            for i, name in enumerate(('H', 'T', 'V')):
+                if timed:
+                    marks[1 + i].record()
                 self.graphs[name].replay()
                 self.graphs['pack' + name].replay()
                 red.reduce_segment(name)                 # asynchronous: travels beside the next segment's graph
@@ -226,8 +241,10 @@ class GraphedTrainStep:
             for name in ('H', 'T', 'V'):
                 red.wait_segment(name)
             ev1.record()
-            if len(self._exposed_ms) < 512:
+            if timed:
+                marks[4] = ev0
                 self._exposed_ms.append((ev0, ev1))
+                self._segment_marks.append(marks)
             self._sync_routed_counts()
             self.g_opt.replay()
         elif self.g_opt is not None:

@@ -117,6 +117,7 @@ SIGNATURES = {
     'vqa_sumsq_multi': (i32, [vp, vp, i32, vp, vp]),
     'vqa_adamw_multi': (i32, [vp, vp, i32, vp, f32, f32, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
     'vqa_amp_update': (i32, [vp, vp, f32, f32, i32, vp]),
+    'vqa_opt_advance_counts': (i32, [vp, vp, i32, vp, vp]),
     'vqa_opt_advance': (i32, [vp, vp, vp]),
     'vqa_adamw_step': (i32, [C.POINTER(VqaAdamWDesc), vp]),
     'vqa_sumsq_f32': (i32, [vp, u64, vp, vp]),

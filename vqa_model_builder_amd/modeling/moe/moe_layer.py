@@ -139,7 +139,8 @@ class MOELayer(nn.Module):
     # on every token and combining with the routing weights (zero where an expert was not chosen) costs no time and needs no
     # host decision.  Outputs and gradients are those of the sparse dispatch; an expert NO token chose gets zero gradients
     # instead of none, and its parameters carry `_vqa_active` (device word = its routed-token count) so that FusedAdamW
-    # leaves them alone exactly as it skips a grad-is-None parameter.
+    # leaves them alone exactly as it skips a grad-is-None parameter, and `_vqa_step` (device word = the number of updates the
+    # expert received) so that its AdamW bias corrections follow ITS step count, as torch's per-parameter `step` does.
     dense_dispatch = False
     parallel_branches = 0          # dense dispatch: experts on side streams (0 off, 1 specialised experts, 2 every expert; profiles/r02/moe.md)
 
@@ -148,9 +149,12 @@ class MOELayer(nn.Module):
         if on and getattr(self, '_active', None) is None:
             dev = self.output_norm.weight.device
             self._active = torch.ones((len(self.experts),), dtype=torch.float32, device=dev)
+            self._steps = torch.zeros((len(self.experts),), dtype=torch.float32, device=dev)     # per-expert update counts (FusedAdamW)
             for e, expert in enumerate(self.experts):
                 for prm in expert.parameters():
                     prm._vqa_active = self._active[e:e + 1]
+                    prm._vqa_step = self._steps[e:e + 1]
+                    prm._vqa_counts = (self._active, self._steps, e)
         return self
 
     def _forward_dense(self, x, mask, w2, i2, B, S, D, kwargs):

@@ -52,7 +52,7 @@ class FusedAdamW(torch.optim.Optimizer):
         the capture, after any eager warm-up steps; all parameters of a group must share one step count."""
         self._hyper = []
         for group in self.param_groups:
-            steps = {int(self.state[p]['step']) for p in group['params'] if p in self.state and self.state[p]}
+            steps = {int(self.state[p]['step']) for p in group['params'] if p in self.state and self.state[p] and not hasattr(p, '_vqa_step')}
             if len(steps) > 1:
                 raise RuntimeError('FusedAdamW.make_capturable: parameters of one group have different step counts')
             self._hyper.append(torch.tensor([float(group['lr']), float(steps.pop() if steps else 0)], dtype=torch.float32).to(device))
@@ -99,7 +99,8 @@ class FusedAdamW(torch.optim.Optimizer):
             n = int(round(float(h[1])))
             for p in group['params']:
                 if p in self.state and self.state[p]:
-                    self.state[p]['step'] = n
+                    own = getattr(p, '_vqa_step', None)      # an expert's parameters: the updates the expert received
+                    self.state[p]['step'] = n if own is None else int(round(float(own)))
 
     def state_dict(self):
         self.sync_step_counts()
@@ -126,6 +127,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.make_capturable(first.device)
         shadows = self._shadow_map()
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
+        counted = {}                                    # MoE layers under dense dispatch: id(steps) -> (active [E], steps [E], {expert: step so far})
         standalone = []
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
@@ -139,8 +141,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     state['step'] = 0
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                prev_step = int(state['step'])
                 if self._hyper is None:                     # capturable mode counts on the device (bias corrections come from there)
-                    state['step'] = int(state['step']) + 1
+                    state['step'] = prev_step + 1
                 sp, sk = shadows.get(id(p), (0, 0))
                 if sp == 0:                                 # stand-alone parameter (tail ops, experts): its cached bf16 copy, if any
                     sh = _ops.standalone_shadow(p)
@@ -149,9 +152,16 @@ class FusedAdamW(torch.optim.Optimizer):
                         standalone.append(p)
                 wd_kind = struct.unpack('<q', struct.pack('<fI', float(group['weight_decay']), sk))[0]
                 act = getattr(p, '_vqa_active', None)       # device word: routed-token count of the parameter's expert (dense MoE dispatch)
+                own = getattr(p, '_vqa_step', None)         # device word: the expert's own update count (bias corrections)
+                if own is not None:
+                    a_all, s_all, e = p._vqa_counts
+                    ent = counted.get(id(s_all))
+                    if ent is None:
+                        ent = counted[id(s_all)] = (a_all, s_all, {})
+                    ent[2].setdefault(e, prev_step)
                 launches.setdefault((gi, state['step']), []).append(
                     (p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
-                     act.data_ptr() if act is not None else 0))
+                     act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0))
                 dev = p.device
         if not launches:
             return loss
@@ -189,6 +199,13 @@ class FusedAdamW(torch.optim.Optimizer):
             self._norm2.zero_()
             for _, _, tab, chunks, nch, _ in tables:
                 K._chk(lib.vqa_sumsq_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr(), st), 'vqa_sumsq_multi')
+        for a_all, s_all, first in counted.values():
+            if not getattr(s_all, '_vqa_seeded', False):   # first sight (never inside a capture: the warm-up steps run eagerly): start
+                for e, n0 in first.items():                 # each expert's device count from what its parameters have received so far
+                    s_all[e:e + 1].fill_(float(n0))
+                s_all._vqa_seeded = True
+            K._chk(lib.vqa_opt_advance_counts(s_all.data_ptr(), a_all.data_ptr(), s_all.numel(), self._norm2.data_ptr() if amp is not None else None, st),
+                   'vqa_opt_advance_counts')
         for group, step, tab, chunks, nch, gi in tables:
             b1, b2 = group['betas']
             hyper = None
