@@ -391,12 +391,13 @@ def main():
             BUS = 300e9                           # assumed all-reduce bus bandwidth of an 8-GPU xGMI node (7 links x ~153 GB/s per GPU, ~30 % of it)
             sb, sm = seg.get('segment_bytes', {}), seg.get('segment_ms', {})
             total = seg['ms_per_step']
-            t_opt = max(0.0, total - sum(sm.get(k, 0.0) for k in 'FHTV'))
+            t_opt = max(0.0, total - sum(sm.values()))
+            blocks = [k for k in sm if k != 'F']                 # in replay order: H, T, V (, V2)
 
             def predict(wire):
                 # one RCCL stream: a block's exchange starts when its graph has finished AND the previous exchange is through
                 ready, end = sm.get('F', 0.0), 0.0
-                for k in 'HTV':
+                for k in blocks:
                     ready += sm.get(k, 0.0)
                     end = max(ready, end) + 2 * (7 / 8) * sb.get(k, 0) * wire / BUS * 1e3
                 exposed = max(0.0, end - ready)

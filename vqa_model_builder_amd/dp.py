@@ -259,8 +259,19 @@ class GradReducer:
             inplace, loose = [], []
             for us, ps in by_storage.values():
                 g0 = ps[0].grad
-                if len(ps) > 1 and all(q.grad.dtype == torch.float32 for q in ps) and us.nbytes() % 4 == 0:
-                    inplace.append(torch.empty(0, dtype=torch.float32, device=g0.device).set_(us, 0, (us.nbytes() // 4,)))
+                if len(ps) > 1 and all(q.grad.dtype == torch.float32 and q.grad.is_contiguous() for q in ps) and us.nbytes() % 4 == 0:
+                    # the segment's gradients inside this arena as maximal contiguous runs (a block whose backward is split over two
+                    # graphs contributes a run of its accumulated slots and a run of its weight slots to each segment; a whole
+                    # block is one run): each run is all-reduced in place
+                    whole = torch.empty(0, dtype=torch.float32, device=g0.device).set_(us, 0, (us.nbytes() // 4,))
+                    spans = sorted((q.grad.storage_offset(), q.grad.storage_offset() + q.grad.numel()) for q in ps)
+                    runs = [list(spans[0])]
+                    for a, e in spans[1:]:
+                        if a <= runs[-1][1] + 8:              # slots are 16-byte aligned: <= 3 floats of padding between neighbours
+                            runs[-1][1] = max(runs[-1][1], e)
+                        else:
+                            runs.append([a, e])
+                    inplace.extend(whole[a:e] for a, e in runs)
                 else:
                     loose.extend(ps)
             pack = None

@@ -44,7 +44,7 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
-                 moe_branches: int = 1):
+                 moe_branches: int = 1, split_vision: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -53,6 +53,7 @@ class GraphedTrainStep:
         ``loss_of(output)`` picks the scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer``
         without hooks attached.  ``parallel_towers``: the vision encoder runs as a parallel branch (measured on MI355X, cfg2,
         B=32: 13.7 -> 10.6 ms/step).  ``defer_wgrad``: weight-gradient GEMMs are issued grouped at the end of their graph.
+        ``split_vision`` (segmented step): the vision encoder's backward as two graphs (upper / lower half of its layers).
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
         ``forward_from_features``): the five-graph data-parallel step described in the module docstring."""
@@ -72,6 +73,13 @@ class GraphedTrainStep:
         if segmented is None:
             segmented = reducer is not None and getattr(reducer, 'world', 1) > 1 and can_segment
         self.segmented = bool(segmented and can_segment and reducer is not None)
+        # the LAST block's exchange is the exposed one: the vision backward is cut once more (upper / lower half of its layers) so
+        # that only half of its arena is left to travel when the step's compute is done
+        self._order, self._vision_split = ('H', 'T', 'V'), None
+        vb = getattr(getattr(model, 'visual_encoder', None), 'backbone', None)
+        if self.segmented and split_vision and vb is not None and hasattr(vb, 'resume_backward') and vb.config.num_hidden_layers >= 2:
+            self._vision_split = vb.config.num_hidden_layers // 2
+            self._order = ('H', 'T', 'V', 'V2')
         self._exposed_ms, self._comm_events, self._replays = [], None, 0
         self._segment_marks = []
         cur = torch.cuda.current_stream()
@@ -81,6 +89,8 @@ class GraphedTrainStep:
             for _ in range(max(1, warmup)):    # at least one eager step in the capture's own configuration (streams, dense MoE dispatch)
                 if self.segmented:
                     self._segment_F(); self._segment_H(); self._segment_T(); self._segment_V()
+                    if self._vision_split is not None:
+                        self._segment_V2()
                 else:
                     self._fwd_bwd()
                 if reducer is not None:
@@ -115,15 +125,17 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_main, **kw):                      # F
                 self._segment_F()
             pool = self.g_main.pool()
-            order = ('H', 'T', 'V')
-            for name, fn in (('H', self._segment_H), ('T', self._segment_T), ('V', self._segment_V)):
+            order = self._order
+            for name, fn in (('H', self._segment_H), ('T', self._segment_T), ('V', self._segment_V), ('V2', self._segment_V2)):
+                if name not in order:
+                    continue
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, **kw):
                     fn()
                 self.graphs[name] = g
             seg_of = {}
             for n, p in model.named_parameters():
-                seg_of[id(p)] = 'V' if n.startswith('visual_encoder.') else 'T' if n.startswith('text_encoder.') else 'H'
+                seg_of[id(p)] = self._vision_segment(n) if n.startswith('visual_encoder.') else 'T' if n.startswith('text_encoder.') else 'H'
             reducer.prepare_static(seg_of, order)
             # the device-side packing of each segment (stand-alone gradients -> pack buffer, bf16 wire copies) is a small graph of
             # its own, replayed right behind the segment's backward graph
@@ -194,14 +206,37 @@ class GraphedTrainStep:
         self._encoder_backward((2, 3))               # (text_pooled, text_sequence)
 
     def _segment_V(self):
-        self._encoder_backward((0, 1))               # (visual_pooled, visual_spatial)
+        vb = self.model.visual_encoder.backbone if self._vision_split is not None else None
+        if vb is not None:
+            vb.split_backward_after = self._vision_split      # the autograd node stops after the upper half of the layers ...
+        try:
+            self._encoder_backward((0, 1))           # (visual_pooled, visual_spatial)
+        finally:
+            if vb is not None:
+                vb.split_backward_after = None
+
+    def _segment_V2(self):
+        from .hip import kernels as K
+        prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
+        try:
+            self.model.visual_encoder.backbone.resume_backward()     # ... and the lower half + embeddings run here
+            K.wgrad_flush_all()
+        finally:
+            K.WGRAD_DEFER_TO_STEP_END = prev_defer
+
+    def _vision_segment(self, name):
+        if self._vision_split is None:
+            return 'V'
+        import re
+        m = re.search(r'\.layers\.(\d+)\.', name)
+        return 'V' if (m is not None and int(m.group(1)) >= self._vision_split) else 'V2'
 
     def describe(self) -> str:
         if self.reducer is None:
             return 'hip-graph (one graph: 2 parallel encoder branches, grouped weight gradients, clip + AdamW)'
         if not self.segmented:
             return 'hip-graph forward+backward, eager all-reduce, hip-graph optimiser'
-        return ('5 hip-graphs (encoders fwd | fusion+head fwd+bwd | text bwd | vision bwd | optimiser); each block\'s gradient arena '
+        return (f'{len(self._order) + 2} hip-graphs (encoders fwd | fusion+head fwd+bwd | text bwd | vision bwd{" upper | lower" if self._vision_split else ""} | optimiser); each block\'s gradient arena '
                 f'all-reduced ({self.reducer.grad_dtype}) beside the next block\'s graph')
 
     def comm_stats(self) -> Dict[str, float]:
@@ -213,7 +248,7 @@ class GraphedTrainStep:
         if self._segment_marks:
             # median GPU time of each graph of the step (F: encoders forward, H: fusion + head forward / backward, T / V: encoder backward)
             seg = {}
-            for j, name in enumerate(('F', 'H', 'T', 'V')):
+            for j, name in enumerate(('F',) + tuple(self._order)):
                 ts = sorted(m[j].elapsed_time(m[j + 1]) for m in self._segment_marks)
                 seg[name] = round(ts[len(ts) // 2], 3)
             out['segment_ms'] = seg
@@ -224,13 +259,14 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 self.static[k].copy_(v, non_blocking=True)
         timed = self.segmented and len(self._exposed_ms) < 512
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        order = self._order
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 2)] if timed else None
         if timed:
             marks[0].record()
         self.g_main.replay()
         if self.segmented:
             red = self.reducer
-            for i, name in enumerate(('H', 'T', 'V')):
+            for i, name in enumerate(order):
                 if timed:
                     marks[1 + i].record()
                 self.graphs[name].replay()
@@ -238,11 +274,11 @@ class GraphedTrainStep:
                 red.reduce_segment(name)                 # asynchronous: travels beside the next segment's graph
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()                                 # all compute of the step is enqueued: what follows is exposed exchange
-            for name in ('H', 'T', 'V'):
+            for name in order:
                 red.wait_segment(name)
             ev1.record()
             if timed:
-                marks[4] = ev0
+                marks[len(order) + 1] = ev0
                 self._exposed_ms.append((ev0, ev1))
                 self._segment_marks.append(marks)
             self._sync_routed_counts()

@@ -160,6 +160,18 @@ class ClipRunner:
         return x.view(B, T, D), saved
 
     def backward(self, saved, dout):
+        gen = self.backward_steps(saved, dout, None)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
+    def backward_steps(self, saved, dout, split_after):
+        """The backward as a generator: with ``split_after = l`` it yields the gradient dict once layers L-1 .. l are done (their
+        LayerNorm partials reduced; their weight-gradient GEMMs queued) and finishes the rest when resumed -- the data-parallel
+        captured step puts the two halves into two graphs so that the upper half's gradients travel while the lower half computes
+        (graph.GraphedTrainStep).  Returns the gradient dict."""
         W, D, H, I = self.W, self.D, self.H, self.I
         B, P = saved['B'], saved['P']
         T, M = P + 1, B * (P + 1)
@@ -168,6 +180,9 @@ class ClipRunner:
         dxb = K.cast_bf16(dx)
         K.colsum_bf16(dxb, M, D, out=G[f'l{self.L - 1}.fc2_b'])          # later layers get it fused into LN1-backward
         for l in reversed(range(self.L)):
+            if split_after is not None and l == split_after - 1 and l >= 0:
+                K.ln_reduce_flush()
+                yield G
             k = f'l{l}.'
             x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g = saved['layers'][l]
             K.linear_dw(dxb, g, M, D, I, out=G[k + 'fc2_w'], prezeroed=False)

@@ -149,9 +149,29 @@ class ClipVisionBackbone(nn.Module):
         self._W.shadows.refresh(px.device)
         return self._runner.forward(px.float())
 
+    # Data-parallel captured step: ``split_backward_after = l`` makes the autograd node run only layers L-1 .. l and hand out the
+    # gradient views (the arena slots of the lower layers are filled by ``resume_backward()``, in the next graph of the step).
+    split_backward_after = None
+    _pending_backward = None
+
     def _hip_backward(self, saved, dout, needs):
-        G = self._runner.backward(saved, dout)
+        if self.split_backward_after is None:
+            G = self._runner.backward(saved, dout)
+        else:
+            gen = self._runner.backward_steps(saved, dout, int(self.split_backward_after))
+            try:
+                G = next(gen)
+                self._pending_backward = gen
+            except StopIteration as done:           # nothing to split (split point outside the layer range)
+                G = done.value
         return [None], _split_grads(self._flat, G)
+
+    def resume_backward(self):
+        gen, self._pending_backward = self._pending_backward, None
+        if gen is None:
+            return
+        for _ in gen:                               # runs to the end (a single resume point)
+            pass
 
     def forward(self, pixel_values):
         _require_cuda(pixel_values, 'ClipVisionBackbone')
