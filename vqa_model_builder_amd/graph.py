@@ -44,7 +44,7 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
-                 moe_branches: int = 1, split_vision: bool = True):
+                 moe_branches: int = 1, split_encoders: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -53,7 +53,7 @@ class GraphedTrainStep:
         ``loss_of(output)`` picks the scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer``
         without hooks attached.  ``parallel_towers``: the vision encoder runs as a parallel branch (measured on MI355X, cfg2,
         B=32: 13.7 -> 10.6 ms/step).  ``defer_wgrad``: weight-gradient GEMMs are issued grouped at the end of their graph.
-        ``split_vision`` (segmented step): the vision encoder's backward as two graphs (upper / lower half of its layers).
+        ``split_encoders`` (segmented step): each encoder's backward as two graphs (upper / lower half of its layers).
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
         ``forward_from_features``): the five-graph data-parallel step described in the module docstring."""
@@ -73,13 +73,18 @@ class GraphedTrainStep:
         if segmented is None:
             segmented = reducer is not None and getattr(reducer, 'world', 1) > 1 and can_segment
         self.segmented = bool(segmented and can_segment and reducer is not None)
-        # the LAST block's exchange is the exposed one: the vision backward is cut once more (upper / lower half of its layers) so
-        # that only half of its arena is left to travel when the step's compute is done
-        self._order, self._vision_split = ('H', 'T', 'V'), None
-        vb = getattr(getattr(model, 'visual_encoder', None), 'backbone', None)
-        if self.segmented and split_vision and vb is not None and hasattr(vb, 'resume_backward') and vb.config.num_hidden_layers >= 2:
-            self._vision_split = vb.config.num_hidden_layers // 2
-            self._order = ('H', 'T', 'V', 'V2')
+        # every encoder's backward is cut once more (upper / lower half of its layers): the upper half's arena leaves while the
+        # lower half computes, and only half of the LAST encoder's arena is left to travel when the step's compute is done
+        self._order, self._splits = ('H', 'T', 'V'), {}
+        if self.segmented and split_encoders:
+            order = ['H']
+            for seg, blk in (('T', getattr(getattr(model, 'text_encoder', None), 'encoder', None)),
+                             ('V', getattr(getattr(model, 'visual_encoder', None), 'backbone', None))):
+                order.append(seg)
+                if blk is not None and hasattr(blk, 'resume_backward') and blk.config.num_hidden_layers >= 2:
+                    self._splits[seg] = (blk, blk.config.num_hidden_layers // 2)
+                    order.append(seg + '2')
+            self._order = tuple(order)
         self._exposed_ms, self._comm_events, self._replays = [], None, 0
         self._segment_marks = []
         cur = torch.cuda.current_stream()
@@ -88,9 +93,9 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):                      # warm-up off the default stream (allocator pools, lazy tables, tile attributes)
             for _ in range(max(1, warmup)):    # at least one eager step in the capture's own configuration (streams, dense MoE dispatch)
                 if self.segmented:
-                    self._segment_F(); self._segment_H(); self._segment_T(); self._segment_V()
-                    if self._vision_split is not None:
-                        self._segment_V2()
+                    self._segment_F()
+                    for name in self._order:
+                        getattr(self, '_segment_' + name)()
                 else:
                     self._fwd_bwd()
                 if reducer is not None:
@@ -126,16 +131,15 @@ class GraphedTrainStep:
                 self._segment_F()
             pool = self.g_main.pool()
             order = self._order
-            for name, fn in (('H', self._segment_H), ('T', self._segment_T), ('V', self._segment_V), ('V2', self._segment_V2)):
-                if name not in order:
-                    continue
+            for name in order:
+                fn = getattr(self, '_segment_' + name)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, **kw):
                     fn()
                 self.graphs[name] = g
             seg_of = {}
             for n, p in model.named_parameters():
-                seg_of[id(p)] = self._vision_segment(n) if n.startswith('visual_encoder.') else 'T' if n.startswith('text_encoder.') else 'H'
+                seg_of[id(p)] = self._segment_of(n)
             reducer.prepare_static(seg_of, order)
             # the device-side packing of each segment (stand-alone gradients -> pack buffer, bf16 wire copies) is a small graph of
             # its own, replayed right behind the segment's backward graph
@@ -202,41 +206,52 @@ class GraphedTrainStep:
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
 
-    def _segment_T(self):
-        self._encoder_backward((2, 3))               # (text_pooled, text_sequence)
-
-    def _segment_V(self):
-        vb = self.model.visual_encoder.backbone if self._vision_split is not None else None
-        if vb is not None:
-            vb.split_backward_after = self._vision_split      # the autograd node stops after the upper half of the layers ...
+    def _split_backward(self, seg, idx):
+        blk, at = self._splits.get(seg, (None, None))
+        if blk is not None:
+            blk.split_backward_after = at               # the autograd node stops after the upper half of the layers ...
         try:
-            self._encoder_backward((0, 1))           # (visual_pooled, visual_spatial)
+            self._encoder_backward(idx)
         finally:
-            if vb is not None:
-                vb.split_backward_after = None
+            if blk is not None:
+                blk.split_backward_after = None
 
-    def _segment_V2(self):
+    def _resume_backward(self, seg):
         from .hip import kernels as K
         prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
-            self.model.visual_encoder.backbone.resume_backward()     # ... and the lower half + embeddings run here
+            self._splits[seg][0].resume_backward()      # ... and the lower half + embeddings run here
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
 
-    def _vision_segment(self, name):
-        if self._vision_split is None:
-            return 'V'
+    def _segment_T(self):
+        self._split_backward('T', (2, 3))            # (text_pooled, text_sequence)
+
+    def _segment_T2(self):
+        self._resume_backward('T')
+
+    def _segment_V(self):
+        self._split_backward('V', (0, 1))            # (visual_pooled, visual_spatial)
+
+    def _segment_V2(self):
+        self._resume_backward('V')
+
+    def _segment_of(self, name):
         import re
-        m = re.search(r'\.layers\.(\d+)\.', name)
-        return 'V' if (m is not None and int(m.group(1)) >= self._vision_split) else 'V2'
+        seg = 'V' if name.startswith('visual_encoder.') else 'T' if name.startswith('text_encoder.') else 'H'
+        if seg in self._splits:
+            m = re.search(r'\.layers?\.(\d+)\.', name)
+            if m is None or int(m.group(1)) < self._splits[seg][1]:
+                seg += '2'                              # lower layers, embeddings, projections
+        return seg
 
     def describe(self) -> str:
         if self.reducer is None:
             return 'hip-graph (one graph: 2 parallel encoder branches, grouped weight gradients, clip + AdamW)'
         if not self.segmented:
             return 'hip-graph forward+backward, eager all-reduce, hip-graph optimiser'
-        return (f'{len(self._order) + 2} hip-graphs (encoders fwd | fusion+head fwd+bwd | text bwd | vision bwd{" upper | lower" if self._vision_split else ""} | optimiser); each block\'s gradient arena '
+        return (f'{len(self._order) + 2} hip-graphs (encoders fwd | fusion+head fwd+bwd | text bwd | vision bwd; encoder backwards cut in {"two" if self._splits else "one"} | optimiser); each block\'s gradient arena '
                 f'all-reduced ({self.reducer.grad_dtype}) beside the next block\'s graph')
 
     def comm_stats(self) -> Dict[str, float]:

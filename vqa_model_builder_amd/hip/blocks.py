@@ -249,6 +249,15 @@ class RobertaRunner:
         return x.view(B, S, D), saved
 
     def backward(self, saved, dout):
+        gen = self.backward_steps(saved, dout, None)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
+    def backward_steps(self, saved, dout, split_after):
+        """Generator form of the backward (see ClipRunner.backward_steps): yields once layers L-1 .. ``split_after`` are done."""
         W, D, H, I = self.W, self.D, self.H, self.I
         B, S, seed, pd, pa, kpm = saved['B'], saved['S'], saved['seed'], saved['pd'], saved['pa'], saved['kpm']
         M = B * S
@@ -256,6 +265,9 @@ class RobertaRunner:
         dev = dx.device
         _, G = self.arena.alloc(dev)
         for l in reversed(range(self.L)):
+            if split_after is not None and l == split_after - 1 and l >= 0:
+                K.ln_reduce_flush()
+                yield G
             k = f'l{l}.'
             st = 8 * (l + 1)
             xb, qkv, ctx, s1, m1, r1, x1b, a, g, s2, m2, r2 = saved['layers'][l]

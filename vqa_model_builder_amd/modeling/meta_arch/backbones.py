@@ -47,6 +47,32 @@ class _BlockFn(torch.autograd.Function):
         return (None, None) + tuple(in_grads) + tuple(pgrads)
 
 
+class _ResumableBackward:
+    """Data-parallel captured step: ``split_backward_after = l`` makes the block's autograd node run only layers L-1 .. l and hand
+    out the gradient views (the arena slots of the lower layers are filled by ``resume_backward()``, in the next graph of the step,
+    so the upper half's gradients travel while the lower half computes: graph.GraphedTrainStep)."""
+    split_backward_after = None
+    _pending_backward = None
+
+    def _run_backward(self, saved, dout):
+        if self.split_backward_after is None:
+            return self._runner.backward(saved, dout)
+        gen = self._runner.backward_steps(saved, dout, int(self.split_backward_after))
+        try:
+            G = next(gen)
+            self._pending_backward = gen
+        except StopIteration as done:               # nothing to split (split point outside the layer range)
+            G = done.value
+        return G
+
+    def resume_backward(self):
+        gen, self._pending_backward = self._pending_backward, None
+        if gen is None:
+            return
+        for _ in gen:                               # runs to the end (a single resume point)
+            pass
+
+
 def _require_cuda(t, what):
     if not t.is_cuda:
         raise RuntimeError(f'{what}: the MI355X HIP path needs tensors on the GPU (got {t.device}); '
@@ -92,7 +118,7 @@ class _ClipEmbeddings(nn.Module):
         self.position_embedding = nn.Embedding((image_size // patch) ** 2 + 1, D)
 
 
-class ClipVisionBackbone(nn.Module):
+class ClipVisionBackbone(_ResumableBackward, nn.Module):
     """CLIP vision tower.  ``forward(pixel_values)`` returns an object with ``.last_hidden_state`` [B,1+P,D]
     (un-normalised, exactly what the reference consumes at vqa_model.py:119-121)."""
 
@@ -149,29 +175,8 @@ class ClipVisionBackbone(nn.Module):
         self._W.shadows.refresh(px.device)
         return self._runner.forward(px.float())
 
-    # Data-parallel captured step: ``split_backward_after = l`` makes the autograd node run only layers L-1 .. l and hand out the
-    # gradient views (the arena slots of the lower layers are filled by ``resume_backward()``, in the next graph of the step).
-    split_backward_after = None
-    _pending_backward = None
-
     def _hip_backward(self, saved, dout, needs):
-        if self.split_backward_after is None:
-            G = self._runner.backward(saved, dout)
-        else:
-            gen = self._runner.backward_steps(saved, dout, int(self.split_backward_after))
-            try:
-                G = next(gen)
-                self._pending_backward = gen
-            except StopIteration as done:           # nothing to split (split point outside the layer range)
-                G = done.value
-        return [None], _split_grads(self._flat, G)
-
-    def resume_backward(self):
-        gen, self._pending_backward = self._pending_backward, None
-        if gen is None:
-            return
-        for _ in gen:                               # runs to the end (a single resume point)
-            pass
+        return [None], _split_grads(self._flat, self._run_backward(saved, dout))
 
     def forward(self, pixel_values):
         _require_cuda(pixel_values, 'ClipVisionBackbone')
@@ -263,7 +268,7 @@ class _RobertaEncoder(nn.Module):
         self.layer = nn.ModuleList(_RobertaLayer(D, inter, eps) for _ in range(L))
 
 
-class RobertaBackbone(nn.Module):
+class RobertaBackbone(_ResumableBackward, nn.Module):
     """RoBERTa encoder as PhoBERT uses it.  ``forward(input_ids, attention_mask)`` -> ``.last_hidden_state`` [B,S,D].
     The pooler exists for state_dict compatibility only (computed by HF, unused by the reference: F9)."""
 
@@ -315,8 +320,7 @@ class RobertaBackbone(nn.Module):
         return self._runner.forward(ids, mask, self.training)
 
     def _hip_backward(self, saved, dout, needs):
-        G = self._runner.backward(saved, dout)
-        return [None, None], _split_grads(self._flat, G)
+        return [None, None], _split_grads(self._flat, self._run_backward(saved, dout))
 
     def forward(self, input_ids, attention_mask=None):
         _require_cuda(input_ids, 'RobertaBackbone')
