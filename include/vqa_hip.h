@@ -169,6 +169,7 @@ typedef struct VqaAttnDesc {
      * (batch, head) exceed the LDS together (Sq = Skv = 100 at Dh = 256: the ObjectDetection expert's queries): the backward then
      * runs as two launches that hand the probabilities / dS over through it. */
     float* ws;
+    int causal;                             /* 1: query i attends keys j <= i only (nn.TransformerDecoder's tgt_mask, generative_vqa_model.py:447-451) */
 } VqaAttnDesc;
 size_t vqa_attention_bwd_ws_floats(int B, int H, int Sq, int Skv, int Dh);
 int vqa_attention_fwd(const VqaAttnDesc* d, vqa_stream_t s);
@@ -195,6 +196,7 @@ typedef struct VqaFusedAttnDesc {
     const uint8_t* key_padding_mask;     /* uint8 [B, Skv], 1 = ignore; or NULL */
     float scale;                         /* 0 => Dh^-0.5 */
     float drop_p; uint64_t drop_seed; uint32_t drop_stream;     /* dropout on the probabilities, keyed as in vqa_attention_fwd */
+    int causal;                          /* as VqaAttnDesc.causal */
 } VqaFusedAttnDesc;
 int vqa_fused_inproj_attention_fwd(const VqaFusedAttnDesc* d, vqa_stream_t s);
 
@@ -210,16 +212,22 @@ int vqa_roberta_embed_fwd(const int64_t* ids, const float* word, const float* po
 int vqa_roberta_embed_bwd(const float* du, const int64_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
                           float* dtype0, int B, int S, int D, int pad_id, int V, int Pmax, vqa_stream_t s);
 
+/* nn.Embedding backward without padding_idx (generative_vqa_model.py:497 answer_embedding, tied with the output projection):
+ * dweight[ids[i], :] += dy[i, :] with atomic adds (ids repeat); dweight fp32 [V, D], zero on entry; ids outside [0, V) are skipped */
+int vqa_embedding_rows_bwd(const float* dy, const int32_t* ids, float* dweight, int n, int D, int V, vqa_stream_t s);
+
 /* ---- loss (vqa_model.py:711-716: F.cross_entropy mean + argmax) ------------------------------------------- */
 /* per-row loss (fp32 [B]) and argmax (int64 [B]); loss_mean (fp32 [2]) = {mean over the rows whose label is not
  * ignore_index (-100, as F.cross_entropy), number of such rows}.  A label outside [0,C) other than -100 (torch: device assert)
- * is never dereferenced: that row's loss is NaN and *ok (optional device int32, caller-initialised to 1) is cleared. */
+ * is never dereferenced: that row's loss is NaN and *ok (optional device int32, caller-initialised to 1) is cleared.
+ * label_smoothing e in [0, 1): row loss = (1 - e) * nll + e * mean_c(-log p_c)  (nn.CrossEntropyLoss(label_smoothing=e), the generative
+ * model's loss, generative_vqa_model.py:507-510); 0 for the classification path. */
 int vqa_softmax_ce_argmax_fwd(const float* logits, int ld, const int64_t* labels, float* row_loss, float* loss_mean,
-                              int64_t* argmax, float* lse, int B, int C, int32_t* ok, vqa_stream_t s);
-/* dlogits = (softmax - onehot) * (*dloss) / nvalid (rows with an ignored / invalid label: 0); nvalid = &loss_mean[1] of the forward
+                              int64_t* argmax, float* lse, int B, int C, int32_t* ok, float label_smoothing, vqa_stream_t s);
+/* dlogits = (softmax - (1 - e) onehot - e / C) * (*dloss) / nvalid (rows with an ignored / invalid label: 0); nvalid = &loss_mean[1] of the forward
  * (NULL: B); outputs fp32 and optional 16-bit copy */
 int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss, const float* nvalid,
-                       float* dlogits, void* dlogits_bf16, int B, int C, vqa_stream_t s);
+                       float* dlogits, void* dlogits_bf16, int B, int C, float label_smoothing, vqa_stream_t s);
 
 /* ---- MoE router + dispatch (router.py:287-366, moe_layer.py:146-168); fp32 throughout ----------------------- */
 /* clean[t,e] = <x[t],gate[e]>;  noisy = clean (+ noise[t,e] * softplus(<x[t],w_noise[e]>) * noise_std when noise != NULL;

@@ -1,7 +1,7 @@
 """Golden-vector generator.  Runs ONLY in the build container, where /root/reference is importable.
 
     mkdir -p /tmp/golden_cwd && cd /tmp/golden_cwd && \
-    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts]
+    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts|generative]
 
 It imports the reference's own ``src.modeling.meta_arch`` / ``src.modeling.moe`` modules (SURVEY.md
 §8c, Appendix C), replaces only the two hub-NAME loaders by local random-weight construction of the
@@ -386,6 +386,106 @@ def run_parts(seed=7):
     print(f'[gen_golden] parts -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
 
 
+GEN_TINY = dict(TINY, gen_vocab=96, gen_heads=4, gen_layers=2, gen_ff=96, answer_len=7)
+GEN_FULL = dict(FULL, gen_vocab=64000, gen_heads=8, gen_layers=6, gen_ff=2048, answer_len=16, batch=2)
+
+
+def build_reference_generative(dims):
+    """The reference's ``GenerativeVQAModel`` (generative_vqa_model.py:479-598) with the two hub-name loaders replaced by local
+    random-weight construction of the same HF classes, as for the classification model."""
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel, RobertaConfig, RobertaModel
+    import src.modeling.meta_arch.generative_vqa_model as gm
+    d = dims
+    clip = lambda name=None: CLIPVisionModel(CLIPVisionConfig(
+        hidden_size=d['D'], intermediate_size=d['vit_inter'], num_hidden_layers=d['vit_layers'], num_attention_heads=d['vit_heads'],
+        image_size=d['image'], patch_size=d['patch'], hidden_act='quick_gelu', layer_norm_eps=1e-5))
+    rob = lambda name=None: RobertaModel(RobertaConfig(
+        vocab_size=d['vocab'], hidden_size=d['D'], num_hidden_layers=d['txt_layers'], num_attention_heads=d['txt_heads'],
+        intermediate_size=d['txt_inter'], max_position_embeddings=d['max_pos'], type_vocab_size=1, pad_token_id=1, bos_token_id=0,
+        eos_token_id=2, layer_norm_eps=1e-5))
+    old_clip, old_auto = transformers.CLIPVisionModel.from_pretrained, gm.AutoModel
+    transformers.CLIPVisionModel.from_pretrained = staticmethod(clip)
+    gm.AutoModel = type('AutoModelStub', (), {'from_pretrained': staticmethod(rob)})
+    try:
+        cfg = gm.GenerativeVQAConfig(hidden_size=d['D'], fusion_dim=d['D'], num_decoder_layers=d['gen_layers'], num_attention_heads=d['gen_heads'],
+                                     decoder_ff_dim=d['gen_ff'], max_answer_length=max(d['answer_len'], 8), fusion_num_heads=d['fusion_heads'],
+                                     fusion_num_layers=d['fusion_layers'], vocab_size=d['gen_vocab'], use_moe=False)
+        model = gm.GenerativeVQAModel(cfg).eval()
+    finally:
+        transformers.CLIPVisionModel.from_pretrained, gm.AutoModel = old_clip, old_auto
+    return model, cfg
+
+
+def make_decoder_inputs(dims, seed):
+    """Teacher-forcing inputs: decoder ids [B, A] starting with BOS, one right-padded row, labels = the next token (-100 on pads)."""
+    B, A, V = dims['batch'], dims['answer_len'], dims['gen_vocab']
+    toks = dw.randint('answer_tokens', (B, A + 1), 3, V, seed)
+    toks[:, 0] = 0
+    dec_in, labels = toks[:, :-1].clone(), toks[:, 1:].clone()
+    dmask = torch.ones(B, A, dtype=torch.int64)
+    if B > 1:
+        cut = max(2, (A * 5) // 8)
+        dmask[1, cut:] = 0
+        dec_in[1, cut:] = 1
+        labels[1, cut - 1:] = -100
+    return dec_in, dmask, labels
+
+
+def run_generative_case(tag, dims, seed, full_logits):
+    model, cfg = build_reference_generative(dims)
+    shapes = dw.shapes_of(model.state_dict())
+    sd = dw.make_state_dict(shapes, seed)
+    model.load_state_dict(sd)
+    px, ids, mask, _ = dw.make_inputs(dims['batch'], dims['seq'], dims['image'], vocab_hi=min(30000, dims['vocab']), num_answers=8, seed=seed)
+    dec_in, dmask, labels = make_decoder_inputs(dims, seed)
+    kw = dict(pixel_values=px, input_ids=ids, attention_mask=mask, decoder_input_ids=dec_in, decoder_attention_mask=dmask, labels=labels)
+    with torch.enable_grad():
+        out = model(**kw)
+        out.loss.backward()
+    logits0 = out.logits.detach().clone()
+    arrays = {'loss': out.loss.detach().numpy(), 'memory': out.encoder_hidden_states.detach().numpy(),
+              'logits' if full_logits else 'logits_sample': (logits0 if full_logits else logits0.flatten()[::97]).numpy(),
+              'argmax': logits0.argmax(-1).numpy()}
+    top2 = logits0.topk(2, dim=-1).values
+    arrays['margin'] = (top2[..., 0] - top2[..., 1]).numpy()
+    grad_names, none_names, grads0 = [], [], {}
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            none_names.append(name)
+            continue
+        grad_names.append(name)
+        g = p.grad.detach()
+        grads0[name] = g.clone()
+        arrays['gnorm/' + name] = np.float64(g.double().norm().item())
+        arrays['g/' + name] = sample_grad(g, True).numpy().copy()
+    rl = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for mode, dt, scale in AC_MODES:                      # the reference itself under autocast: the tolerance contract
+        model.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            with torch.autocast('cpu', dtype=dt):
+                o = model(**kw)
+            (o.loss.float() * scale).backward()
+        l1 = o.logits.detach().float()
+        arrays[mode + '/logits_rel_l2'] = np.float64(rl(l1, logits0))
+        arrays[mode + '/loss_abs'] = np.float64(abs(float(o.loss) - float(out.loss)))
+        named = dict(model.named_parameters())
+        arrays[mode + '/gs'] = np.array([rl(sample_grad(named[n].grad.detach().float() / scale, True), sample_grad(grads0[n], True)) for n in grad_names])
+        num = sum((e * float(arrays['gnorm/' + n])) ** 2 for e, n in zip(arrays[mode + '/gs'], grad_names))
+        den = sum(float(arrays['gnorm/' + n]) ** 2 for n in grad_names)
+        print(f'[gen_golden] {tag}: reference under autocast {mode[3:]}: logits rel-L2 {float(arrays[mode + "/logits_rel_l2"]):.2e}, '
+              f'gradients aggregate {np.sqrt(num / den):.2e}')
+    model.zero_grad(set_to_none=True)
+    meta = dict(tag=tag, dims=dims, seed=seed, shapes={k: list(v) for k, v in shapes.items()}, keys=list(shapes), grad_names=grad_names,
+                none_grad_names=none_names, weights_checksum=dw.checksum(sd), torch=torch.__version__,
+                transformers=__import__('transformers').__version__)
+    arrays['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f'{tag}.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'[gen_golden] {tag}: loss={float(out.loss):.6f} params={sum(p.numel() for p in model.parameters())} -> {path} '
+          f'({os.path.getsize(path) / 1e3:.0f} kB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='all')
@@ -411,6 +511,10 @@ def main():
         run_model_case('full32_cfg1_concat', F32, 'concat', 0, 31, False, pool=192, emulate=False)
         run_model_case('full32_cfg2_xattn', F32, 'cross_attention', 0, 32, False, pool=192, emulate=False)
         run_model_case('full32_cfg3_mcan_moe4', F32, 'mcan', 4, 33, False, pool=192, emulate=False)
+    if args.only in ('all', 'generative'):
+        # the generative model: tiny with full logits, full-size (64 000-way head) with a logits sample
+        run_generative_case('generative_tiny', GEN_TINY, 41, True)
+        run_generative_case('generative_full', GEN_FULL, 42, False)
 
 
 if __name__ == '__main__':

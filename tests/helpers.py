@@ -61,3 +61,19 @@ def collect_from_workers(q, procs, n, timeout=120):
                     p.terminate()
             raise AssertionError(f'no result from the workers within {timeout} s')
     return out
+
+
+def build_generative_model(dims, **overrides):
+    """The HIP GenerativeVQAModel with the architecture of a generative fixture (oracle/gen_golden.py: GEN_TINY / GEN_FULL)."""
+    from vqa_model_builder_amd.modeling.meta_arch.generative_vqa_model import GenerativeVQAConfig, GenerativeVQAModel
+    d = dims
+    cfg = GenerativeVQAConfig(
+        hidden_size=d['D'], fusion_dim=d['D'], num_decoder_layers=d['gen_layers'], num_attention_heads=d['gen_heads'], decoder_ff_dim=d['gen_ff'],
+        max_answer_length=max(d['answer_len'], 8), fusion_num_heads=d['fusion_heads'], fusion_num_layers=d['fusion_layers'], vocab_size=d['gen_vocab'],
+        visual_arch=dict(hidden_size=d['D'], intermediate_size=d['vit_inter'], num_hidden_layers=d['vit_layers'], num_attention_heads=d['vit_heads'],
+                         image_size=d['image'], patch_size=d['patch']),
+        text_arch=dict(vocab_size=d['vocab'], hidden_size=d['D'], num_hidden_layers=d['txt_layers'], num_attention_heads=d['txt_heads'],
+                       intermediate_size=d['txt_inter'], max_position_embeddings=d['max_pos'], type_vocab_size=1, pad_token_id=1))
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return GenerativeVQAModel(cfg)

@@ -109,12 +109,31 @@ def test_install_as_src_does_not_hide_the_reference_generative_model():
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
-def test_generative_names_fail_loudly_without_the_reference():
+def test_generative_names_resolve_to_the_hip_implementation():
+    """The five generative names are served lazily by this package's own generative_vqa_model (same dataclass fields and defaults as
+    the reference's config, same ``state_dict`` keys in the same order as the fixture the reference produced); a configuration
+    the HIP build does not cover fails loudly at construction."""
+    import dataclasses
+    import json
+    import numpy as np
     import vqa_model_builder_amd.modeling.meta_arch as ma
-    with pytest.raises(ImportError, match='generative'):
-        ma.GenerativeVQAModel
-    with pytest.raises(ImportError):
-        from vqa_model_builder_amd.modeling.meta_arch import create_generative_vqa_model  # noqa: F401
+    from oracle.gen_golden import GEN_TINY as d
+    cfg = ma.GenerativeVQAConfig(freeze_visual_encoder=True)
+    assert cfg.freeze_visual and cfg.decoder_hidden_dim == cfg.hidden_size and cfg.vocab_size == 64000 and cfg.label_smoothing == 0.1
+    assert {f.name for f in dataclasses.fields(cfg)} >= {'visual_backbone', 'text_encoder', 'num_decoder_layers', 'decoder_ff_dim', 'fusion_num_layers',
+                                                       'use_moe', 'moe_type', 'moe_position', 'tie_word_embeddings', 'max_answer_length'}
+    assert ma.get_default_generative_vqa_config(num_vision_experts=3).num_vision_experts == 3
+    meta = json.loads(str(np.load(os.path.join(REPO, 'tests', 'golden', 'generative_tiny.npz'))['meta']))
+    from tests.helpers import build_generative_model
+    model = build_generative_model(d)
+    assert list(model.state_dict().keys()) == meta['keys']
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == meta['shapes']
+    assert model.decoder.output_projection.weight is model.answer_embedding.weight and model.decoder.embedding is model.answer_embedding
+    with pytest.raises(NotImplementedError, match='sparse'):
+        build_generative_model(d, use_moe=True, moe_type='sparse')
+    with pytest.raises(RuntimeError, match='GPU'):
+        import torch
+        model(pixel_values=torch.zeros(1, 3, d['image'], d['image']), input_ids=torch.zeros(1, 4, dtype=torch.long), attention_mask=torch.ones(1, 4))
 
 
 def _stub_model():

@@ -78,6 +78,53 @@ def test_oracle_matches_reference_full_batch32(tag):
     _check(tag, False)
 
 
+@pytest.mark.parametrize('tag', ['generative_tiny', 'generative_full'])
+def test_generative_oracle_matches_reference(tag):
+    """oracle/gen_oracle.py (concatenated-sequence pre-LN fusion, causal pre-LN decoder, tied 64 000-way head, label-smoothed CE
+    with ignore_index) against what the reference's own GenerativeVQAModel produced: logits, loss, memory, every gradient."""
+    import torch
+    from oracle import det_weights as dw
+    from oracle import gen_oracle as go
+    arrays, meta = load_golden(tag)
+    d = meta['dims']
+    sd0 = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
+    assert dw.checksum(sd0) == meta['weights_checksum']
+    sd = go.tie(sd0)
+    leaves = {}
+    for k, v in sd.items():
+        if k in ('decoder.embedding.weight', 'decoder.output_projection.weight'):
+            continue
+        leaves[k] = v.clone().requires_grad_(v.is_floating_point() and k != 'decoder.pos_encoding.pe')
+    leaves['decoder.embedding.weight'] = leaves['decoder.output_projection.weight'] = leaves['answer_embedding.weight']
+    px, ids, mask, dec_in, dmask, labels = go.fixture_inputs(meta)
+    logits, loss, memory = go.generative_forward(leaves, px, ids, mask, dec_in, dmask, labels, vit_heads=d['vit_heads'], text_heads=d['txt_heads'],
+                                                 fusion_heads=d['fusion_heads'], decoder_heads=d['gen_heads'])
+    loss.backward()
+    rl = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()) / (np.linalg.norm(np.asarray(b, np.float64)) + 1e-30))
+    if 'logits' in arrays:
+        assert rl(logits.detach().numpy(), arrays['logits']) < 1e-5
+    else:
+        assert rl(logits.detach().flatten()[::97].numpy(), arrays['logits_sample']) < 1e-5
+    assert np.array_equal(logits.detach().argmax(-1).numpy(), arrays['argmax']) or float(arrays['margin'].min()) < 1e-4
+    assert abs(float(loss) - float(arrays['loss'])) < 1e-5 * max(1.0, abs(float(arrays['loss'])))
+    assert rl(memory.detach().numpy(), arrays['memory']) < 1e-5
+    from oracle.gen_golden import sample_grad
+    n = 0
+    gmax = max(float(arrays['gnorm/' + name]) for name in meta['grad_names'])
+    for name in meta['grad_names']:
+        key = 'answer_embedding.weight' if name in ('decoder.embedding.weight', 'decoder.output_projection.weight') else name
+        g = leaves[key].grad
+        assert g is not None, name
+        if float(arrays['gnorm/' + name]) < 1e-6 * gmax:          # mathematically zero (key bias under softmax): rounding noise on both sides
+            assert float(g.double().norm()) < 1e-5 * gmax, name
+            continue
+        assert abs(float(g.double().norm()) - float(arrays['gnorm/' + name])) <= 2e-5 * float(arrays['gnorm/' + name]) + 1e-9, name
+        small = float(arrays['gnorm/' + name]) < 1e-4 * gmax         # fp32 summation-order noise is relative to the LARGE terms that cancel in it
+        assert rl(sample_grad(g, True).numpy(), arrays['g/' + name]) < (2e-3 if small else 2e-4), name
+        n += 1
+    assert n > 50
+
+
 def test_fixtures_carry_the_reference_autocast_envelopes():
     """Every model fixture stores what the reference itself does under torch.autocast (bf16 and fp16): the GPU parity gates
     are multiples of THESE numbers.  Sanity: fp16 is the tighter one, and both are finite and in a plausible band."""

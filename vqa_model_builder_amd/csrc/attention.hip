@@ -25,6 +25,7 @@ struct AttnArgs {
     // queries): mode 1 = phase A alone (K, V in LDS; q / dO rows from global; P', dS to the workspace), mode 2 = phase B alone
     // (Q, dO in LDS; P', dS read back).  mode 0 = both phases in one launch, everything in LDS.
     int mode; float* ws;
+    int causal;
 };
 
 // orders this wave's own LDS writes before its following cross-lane LDS reads (per-wave scratch rows)
@@ -56,8 +57,9 @@ __device__ __forceinline__ void row_softmax(const AttnArgs& a, const float* qrow
                                             int lane, float& p0, float& p1, float& ks0, float& ks1) {
     const int j0 = lane, j1 = lane + 64;
     float s0 = -INFINITY, s1 = -INFINITY;
-    if (j0 < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + j0])) s0 = dot_row(qrow, Ks + j0 * pitch, a.Dh) * a.scale;
-    if (j1 < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + j1])) s1 = dot_row(qrow, Ks + j1 * pitch, a.Dh) * a.scale;
+    const int jmax = a.causal ? min(a.Skv, qi + 1) : a.Skv;          // causal: query qi sees keys 0 .. qi
+    if (j0 < jmax && !(a.mask && a.mask[(size_t)b * a.Skv + j0])) s0 = dot_row(qrow, Ks + j0 * pitch, a.Dh) * a.scale;
+    if (j1 < jmax && !(a.mask && a.mask[(size_t)b * a.Skv + j1])) s1 = dot_row(qrow, Ks + j1 * pitch, a.Dh) * a.scale;
     const float m = wave_max(fmaxf(s0, s1));
     const float e0 = (s0 == -INFINITY) ? 0.f : __expf(s0 - m);
     const float e1 = (s1 == -INFINITY) ? 0.f : __expf(s1 - m);
@@ -200,6 +202,7 @@ int fill_args(const VqaAttnDesc* d, AttnArgs& a, bool bwd) {
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv; a.Dh = d->Dh;
     a.mask = d->key_padding_mask;
+    a.causal = d->causal;
     a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)d->Dh);
     a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     a.seed = d->drop_seed; a.stream = d->drop_stream;

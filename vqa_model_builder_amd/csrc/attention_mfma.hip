@@ -150,6 +150,7 @@ bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo; a.ldd_o = d->ldd_o; a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
     a.mask = d->key_padding_mask;
+    a.causal = d->causal;
     a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)d->Dh);
     a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     a.seed = d->drop_seed; a.stream = d->drop_stream;

@@ -15,6 +15,7 @@ struct MArgs {
     float scale, drop_p, inv_keep;
     uint64_t seed; uint32_t stream;
     float *dq_cs, *dk_cs, *dv_cs;       // optional bias-gradient accumulators [H*Dh]
+    int causal;                         // 1: query q attends keys kv <= q only (decoder self-attention)
 };
 
 // column sums of one wave's 16 x 4 slab (lane (i, g) holds row i, columns 4g..4g+3 of the bf16 values it just stored):
@@ -89,7 +90,7 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kv = 16 * t + 4 * g + r;
-            const bool ok = kv < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + kv]);
+            const bool ok = kv < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + kv]) && !(a.causal && kv > 16 * w + (lane & 15));
             s[t][r] = ok ? s[t][r] * a.scale : -INFINITY;
             m = fmaxf(m, s[t][r]);
         }

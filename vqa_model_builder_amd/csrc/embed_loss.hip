@@ -49,11 +49,22 @@ __global__ void roberta_embed_bwd_kernel(const float* __restrict__ du, const int
     }
 }
 
+// nn.Embedding backward without padding_idx (the generative decoder's tied token table): dweight[ids[i], :] += dy[i, :]; ids repeat
+// (BOS in every row, pads), so the adds are atomic.  dweight zero on entry.
+__global__ void embedding_rows_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ ids, float* __restrict__ dweight, int n, int D, int V) {
+    const size_t total = (size_t)n * D, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int i = (int)(t / D), d = (int)(t % D);
+        const int id = ids[i];
+        if (id >= 0 && id < V) atomicAdd(dweight + (size_t)id * D + d, dy[t]);
+    }
+}
+
 // ---- cross entropy: one 256-thread block per row (a wave per row walked the 3000 classes in 47 dependent steps, twice: 23 us) ----
 constexpr int64_t VQA_IGNORE_INDEX = -100;
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels, float* __restrict__ row_loss,
-                              int64_t* __restrict__ argmax, float* __restrict__ lse_out, int B, int C, int32_t* __restrict__ ok) {
-    __shared__ float sm[4]; __shared__ int si[4]; __shared__ float ss[4];
+                              int64_t* __restrict__ argmax, float* __restrict__ lse_out, int B, int C, int32_t* __restrict__ ok, float smooth) {
+    __shared__ float sm[4]; __shared__ int si[4]; __shared__ float ss[4]; __shared__ float sx[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x;
     const float* x = logits + (size_t)row * ld;
     float m = -INFINITY; int mi = 0x7fffffff;
@@ -71,10 +82,11 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         const float om = sm[w]; const int oi = si[w];
         if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
     }
-    float sum = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) sum += __expf(x[c] - m);
+    float sum = 0.f, xs = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float v = x[c]; sum += __expf(v - m); xs += v; }
     sum = wave_sum(sum);
-    if (lane == 0) ss[wave] = sum;
+    if (smooth > 0.f) xs = wave_sum(xs);
+    if (lane == 0) { ss[wave] = sum; sx[wave] = xs; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const float lse = m + __logf(ss[0] + ss[1] + ss[2] + ss[3]);
@@ -87,8 +99,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
             float l = 0.f;
             if (labels) {
                 const int64_t y = labels[row];
-                if (y >= 0 && y < C) l = lse - x[y];
-                else if (y != VQA_IGNORE_INDEX) { l = __builtin_nanf(""); if (ok) *ok = 0; }
+                if (y >= 0 && y < C) {
+                    l = lse - x[y];
+                    // label smoothing (nn.CrossEntropyLoss(label_smoothing=e), generative_vqa_model.py:507-510):
+                    // (1 - e) * nll + e * mean_c(-log p_c),  mean_c(-log p_c) = lse - mean_c(x_c)
+                    if (smooth > 0.f) l = (1.f - smooth) * l + smooth * (lse - (sx[0] + sx[1] + sx[2] + sx[3]) / (float)C);
+                } else if (y != VQA_IGNORE_INDEX) { l = __builtin_nanf(""); if (ok) *ok = 0; }
             }
             row_loss[row] = l;
         }
@@ -96,16 +112,20 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 }
 
 // mean over the rows whose label is not ignore_index (0 valid rows: 0/0 = NaN, as torch)
-__global__ void ce_mean_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, float* __restrict__ loss_mean, int B) {
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, float* __restrict__ loss_mean, int B) {
+    __shared__ float sa[4], sc[4];
     float acc = 0.f, cnt = 0.f;
-    for (int i = threadIdx.x; i < B; i += 64) { acc += row_loss[i]; cnt += labels[i] != VQA_IGNORE_INDEX ? 1.f : 0.f; }
+    for (int i = threadIdx.x; i < B; i += 256) { acc += row_loss[i]; cnt += labels[i] != VQA_IGNORE_INDEX ? 1.f : 0.f; }
     acc = wave_sum(acc); cnt = wave_sum(cnt);
-    if (threadIdx.x == 0) { loss_mean[0] = acc / cnt; loss_mean[1] = cnt; }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = acc; sc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) { const float n = sc[0] + sc[1] + sc[2] + sc[3]; loss_mean[0] = (sa[0] + sa[1] + sa[2] + sa[3]) / n; loss_mean[1] = n; }
 }
 
 __global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels, const float* __restrict__ lse,
                               const float* __restrict__ dloss, const float* __restrict__ nvalid, float* __restrict__ dlogits, h16_t* __restrict__ dlb,
-                              int B, int C) {
+                              int B, int C, float smooth) {
+    const float on = 1.f - smooth, off = smooth / (float)C;
     const float scale = dloss[0] / (nvalid ? nvalid[0] : (float)B);
     const size_t total = (size_t)B * C, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -113,8 +133,8 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, int ld, const in
         const int64_t y = labels[r];
         float g = 0.f;
         if (y >= 0 && y < C) {                               // ignored / invalid rows get no gradient
-            g = __expf(logits[(size_t)r * ld + c] - lse[r]);
-            if (y == c) g -= 1.f;
+            g = __expf(logits[(size_t)r * ld + c] - lse[r]) - off;
+            if (y == c) g -= on;
             g *= scale;
         }
         if (dlogits) dlogits[t] = g;
@@ -147,24 +167,32 @@ int vqa_roberta_embed_bwd(const float* du, const int64_t* ids, const int32_t* po
     return vqa_colsum_f32(du, B * S, D, D, dtype0, s);
 }
 
+int vqa_embedding_rows_bwd(const float* dy, const int32_t* ids, float* dweight, int n, int D, int V, vqa_stream_t s) {
+    if (!dy || !ids || !dweight || n <= 0 || D <= 0 || V <= 0) return VQA_ERR_ARG;
+    size_t g = ((size_t)n * D + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(embedding_rows_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, dy, ids, dweight, n, D, V);
+    return (int)hipGetLastError();
+}
+
 int vqa_softmax_ce_argmax_fwd(const float* logits, int ld, const int64_t* labels, float* row_loss, float* loss_mean, int64_t* argmax,
-                              float* lse, int B, int C, int32_t* ok, vqa_stream_t s) {
-    if (!logits || B <= 0 || C <= 0 || (loss_mean && !row_loss)) return VQA_ERR_ARG;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, logits, ld, labels, row_loss, argmax, lse, B, C, ok);
+                              float* lse, int B, int C, int32_t* ok, float label_smoothing, vqa_stream_t s) {
+    if (!logits || B <= 0 || C <= 0 || (loss_mean && !row_loss) || label_smoothing < 0.f || label_smoothing >= 1.f) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)s, logits, ld, labels, row_loss, argmax, lse, B, C, ok, label_smoothing);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (loss_mean && labels) {
-        hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, row_loss, labels, loss_mean, B);
+        hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, row_loss, labels, loss_mean, B);
         e = hipGetLastError();
     }
     return (int)e;
 }
 
 int vqa_softmax_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* lse, const float* dloss, const float* nvalid,
-                       float* dlogits, void* dlogits_bf16, int B, int C, vqa_stream_t s) {
-    if (!logits || !labels || !lse || !dloss || (!dlogits && !dlogits_bf16)) return VQA_ERR_ARG;
-    size_t g = ((size_t)B * C + 255) / 256; if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, logits, ld, labels, lse, dloss, nvalid, dlogits, (h16_t*)dlogits_bf16, B, C);
+                       float* dlogits, void* dlogits_bf16, int B, int C, float label_smoothing, vqa_stream_t s) {
+    if (!logits || !labels || !lse || !dloss || (!dlogits && !dlogits_bf16) || label_smoothing < 0.f || label_smoothing >= 1.f) return VQA_ERR_ARG;
+    size_t g = ((size_t)B * C + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, logits, ld, labels, lse, dloss, nvalid, dlogits, (h16_t*)dlogits_bf16, B, C,
+                       label_smoothing);
     return (int)hipGetLastError();
 }
 

@@ -992,6 +992,7 @@ extern "C" int vqa_fused_inproj_attention_fwd(const VqaFusedAttnDesc* d, vqa_str
     MArgs& a = p.a;
     a.o = (h16_t*)d->o; a.ldo = d->ldo; a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
     a.mask = d->key_padding_mask;
+    a.causal = d->causal;
     a.scale = d->scale != 0.f ? d->scale : 1.0f / sqrtf((float)dh);
     a.drop_p = d->drop_p; a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     a.seed = d->drop_seed; a.stream = d->drop_stream;

@@ -387,7 +387,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, rows, cols, *, dres=None, want_f32=T
 
 # ---- attention ---------------------------------------------------------------------------------------------------
 
-def attention_fwd(q, k, v, ldq, ldk, ldv, B, H, Sq, Skv, Dh, mask_u8=None, drop: Drop = NO_DROP, out=None):
+def attention_fwd(q, k, v, ldq, ldk, ldv, B, H, Sq, Skv, Dh, mask_u8=None, drop: Drop = NO_DROP, out=None, causal=False):
     if out is None:
         out = torch.empty((B * Sq, H * Dh), dtype=HALF(), device=q.device)
     d = _ad
@@ -397,12 +397,13 @@ def attention_fwd(q, k, v, ldq, ldk, ldv, B, H, Sq, Skv, Dh, mask_u8=None, drop:
     d.key_padding_mask, d.scale = _p(mask_u8), 0.0
     d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
     d.d_o = d.dq = d.dk = d.dv = None
+    d.causal = int(causal)
     _chk(L().vqa_attention_fwd(C.byref(d), _stream()), 'vqa_attention_fwd')
     return out
 
 
 def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, lddq, lddk, lddv, mask_u8=None,
-                  drop: Drop = NO_DROP, dq_colsum=None, dk_colsum=None, dv_colsum=None):
+                  drop: Drop = NO_DROP, dq_colsum=None, dk_colsum=None, dv_colsum=None, causal=False):
     """``d*_colsum`` (fp32 [H*Dh], zero on entry -- gradient-arena slots): bias gradients of the Q/K/V projections, fused."""
     d = _ad
     d.q, d.k, d.v, d.o = _p(q), _p(k), _p(v), None
@@ -416,6 +417,7 @@ def attention_bwd(q, k, v, d_o, ldq, ldk, ldv, B, H, Sq, Skv, Dh, dq, dk, dv, ld
     nws = L().vqa_attention_bwd_ws_floats(B, H, Sq, Skv, Dh)
     ws = torch.empty((nws,), dtype=F32, device=q.device) if nws else None
     d.ws = _p(ws)
+    d.causal = int(causal)
     _chk(L().vqa_attention_bwd(C.byref(d), _stream()), 'vqa_attention_bwd')
     d.dq_colsum = d.dk_colsum = d.dv_colsum = d.ws = None
 
@@ -430,7 +432,7 @@ def fused_attention_covers(D, H, Sq, Skv):
 
 
 def fused_inproj_attention_fwd(xq, xkv, w_in, b_in, B, H, Sq, Skv, D, mask_u8=None, drop: Drop = NO_DROP, *, q=None, k=None, v=None,
-                               ldq=None, ldk=None, ldv=None, ldxq=None, ldxkv=None, out=None):
+                               ldq=None, ldk=None, ldv=None, ldxq=None, ldxkv=None, out=None, causal=False):
     """attention(xq Wq^T + bq, xkv Wk^T + bk, xkv Wv^T + bv) per (sample, head) in ONE launch (csrc/fused_attn.h); ``q`` / ``k`` /
     ``v``: optional bf16 destinations of the projections (what backward reads).  Returns the bf16 context [B*Sq, D]."""
     if out is None:
@@ -444,6 +446,7 @@ def fused_inproj_attention_fwd(xq, xkv, w_in, b_in, B, H, Sq, Skv, D, mask_u8=No
     d.B, d.H, d.Sq, d.Skv, d.D = B, H, Sq, Skv, D
     d.key_padding_mask, d.scale = _p(mask_u8), 0.0
     d.drop_p, d.drop_seed, d.drop_stream = drop.p, drop.seed, drop.stream
+    d.causal = int(causal)
     _chk(L().vqa_fused_inproj_attention_fwd(C.byref(d), _stream()), 'vqa_fused_inproj_attention_fwd')
     return out
 
@@ -514,22 +517,22 @@ def roberta_embed_bwd(du, ids, pos_ids, dword, dpos, dtype0, B, S, D, pad_id=1):
 
 # ---- loss ------------------------------------------------------------------------------------------------------------
 
-def ce_argmax_fwd(logits, labels, B, Cn):
+def ce_argmax_fwd(logits, labels, B, Cn, label_smoothing=0.0):
     dev = logits.device
     row_loss = torch.empty((B,), dtype=F32, device=dev)
     loss2 = torch.empty((2,), dtype=F32, device=dev)          # {mean over the non-ignored rows, their count}
     pred = torch.empty((B,), dtype=torch.int64, device=dev)
     lse = torch.empty((B,), dtype=F32, device=dev)
     _chk(L().vqa_softmax_ce_argmax_fwd(_p(logits), Cn, _p(labels), _p(row_loss), _p(loss2) if labels is not None else None,
-                                       _p(pred), _p(lse), B, Cn, _p(status_word(dev)), _stream()), 'vqa_softmax_ce_argmax_fwd')
+                                       _p(pred), _p(lse), B, Cn, _p(status_word(dev)), float(label_smoothing), _stream()), 'vqa_softmax_ce_argmax_fwd')
     return (loss2[0] if labels is not None else None), pred, lse, (loss2[1:] if labels is not None else None)
 
 
-def ce_bwd(logits, labels, lse, dloss, B, Cn, nvalid=None, want_f32=True, want_bf16=False):
+def ce_bwd(logits, labels, lse, dloss, B, Cn, nvalid=None, want_f32=True, want_bf16=False, label_smoothing=0.0):
     dev = logits.device
     dl = torch.empty((B, Cn), dtype=F32, device=dev) if want_f32 else None
     dlb = torch.empty((B, Cn), dtype=HALF(), device=dev) if want_bf16 else None
-    _chk(L().vqa_softmax_ce_bwd(_p(logits), Cn, _p(labels), _p(lse), _p(dloss), _p(nvalid), _p(dl), _p(dlb), B, Cn, _stream()),
+    _chk(L().vqa_softmax_ce_bwd(_p(logits), Cn, _p(labels), _p(lse), _p(dloss), _p(nvalid), _p(dl), _p(dlb), B, Cn, float(label_smoothing), _stream()),
          'vqa_softmax_ce_bwd')
     return dl, dlb
 

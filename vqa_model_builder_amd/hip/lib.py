@@ -26,14 +26,14 @@ class VqaAttnDesc(C.Structure):
                 ('B', i32), ('H', i32), ('Sq', i32), ('Skv', i32), ('Dh', i32), ('key_padding_mask', vp),
                 ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32),
                 ('d_o', vp), ('ldd_o', i32), ('dq', vp), ('dk', vp), ('dv', vp),
-                ('lddq', i32), ('lddk', i32), ('lddv', i32), ('dq_colsum', vp), ('dk_colsum', vp), ('dv_colsum', vp), ('ws', vp)]
+                ('lddq', i32), ('lddk', i32), ('lddv', i32), ('dq_colsum', vp), ('dk_colsum', vp), ('dv_colsum', vp), ('ws', vp), ('causal', i32)]
 
 
 class VqaFusedAttnDesc(C.Structure):
     _fields_ = [('xq', vp), ('ldxq', i32), ('xkv', vp), ('ldxkv', i32), ('w_in', vp), ('ldw', i32), ('b_in', vp),
                 ('q', vp), ('k', vp), ('v', vp), ('ldq', i32), ('ldk', i32), ('ldv', i32), ('o', vp), ('ldo', i32),
                 ('B', i32), ('H', i32), ('Sq', i32), ('Skv', i32), ('D', i32), ('key_padding_mask', vp),
-                ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32)]
+                ('scale', f32), ('drop_p', f32), ('drop_seed', u64), ('drop_stream', u32), ('causal', i32)]
 
 
 class VqaGemmGroupItem(C.Structure):
@@ -80,8 +80,9 @@ SIGNATURES = {
     'vqa_attention_bwd': (i32, [C.POINTER(VqaAttnDesc), vp]),
     'vqa_roberta_embed_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     'vqa_roberta_embed_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    'vqa_softmax_ce_argmax_fwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
-    'vqa_softmax_ce_bwd': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'vqa_embedding_rows_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    'vqa_softmax_ce_argmax_fwd': (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, f32, vp]),
+    'vqa_softmax_ce_bwd': (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     'vqa_router_gate_fwd': (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_router_gate_bwd': (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_router_topk_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -170,30 +170,30 @@ def layer_norm(x, weight, bias, eps=1e-5):
 
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, num_heads, mask_u8, drop):
+    def forward(ctx, q, k, v, num_heads, mask_u8, drop, causal=False):
         # q [B,Sq,D], k/v [B,Skv,D] fp32
         B, Sq, D = q.shape
         Skv = k.shape[1]
         qb, kb, vb = _as_bf16(q.reshape(-1, D).contiguous()), _as_bf16(k.reshape(-1, D).contiguous()), _as_bf16(v.reshape(-1, D).contiguous())
-        o = K.attention_fwd(qb, kb, vb, D, D, D, B, num_heads, Sq, Skv, D // num_heads, mask_u8, drop)
+        o = K.attention_fwd(qb, kb, vb, D, D, D, B, num_heads, Sq, Skv, D // num_heads, mask_u8, drop, causal=causal)
         ctx.save_for_backward(qb, kb, vb, mask_u8)
-        ctx.meta = (B, Sq, Skv, D, num_heads, drop)
+        ctx.meta = (B, Sq, Skv, D, num_heads, drop, causal)
         return K.cast_f32(o).view(B, Sq, D)
 
     @staticmethod
     def backward(ctx, do):
         qb, kb, vb, mask_u8 = ctx.saved_tensors
-        B, Sq, Skv, D, H, drop = ctx.meta
+        B, Sq, Skv, D, H, drop, causal = ctx.meta
         dob = _as_bf16(do.reshape(-1, D).contiguous())
         dq = torch.empty((B * Sq, D), dtype=K.HALF(), device=do.device)
         dk = torch.empty((B * Skv, D), dtype=K.HALF(), device=do.device)
         dv = torch.empty((B * Skv, D), dtype=K.HALF(), device=do.device)
-        K.attention_bwd(qb, kb, vb, dob, D, D, D, B, H, Sq, Skv, D // H, dq, dk, dv, D, D, D, mask_u8, drop)
-        return K.cast_f32(dq).view(B, Sq, D), K.cast_f32(dk).view(B, Skv, D), K.cast_f32(dv).view(B, Skv, D), None, None, None
+        K.attention_bwd(qb, kb, vb, dob, D, D, D, B, H, Sq, Skv, D // H, dq, dk, dv, D, D, D, mask_u8, drop, causal=causal)
+        return K.cast_f32(dq).view(B, Sq, D), K.cast_f32(dk).view(B, Skv, D), K.cast_f32(dv).view(B, Skv, D), None, None, None, None
 
 
 def multi_head_attention(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, num_heads, key_padding_mask=None,
-                         dropout_p=0.0, training=False):
+                         dropout_p=0.0, training=False, causal=False):
     """nn.MultiheadAttention (batch_first, packed in_proj), the averaged attention map it also returns is never
     consumed on this path (reference discards it) and is not computed."""
     D = in_proj_weight.shape[1]
@@ -207,7 +207,7 @@ def multi_head_attention(query, key, value, in_proj_weight, in_proj_bias, out_w,
         k, v = kv[..., :D], kv[..., D:]
     mask = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
     drop = Drop(dropout_p, new_seed(), 77) if (training and dropout_p > 0) else NO_DROP
-    ctx = _AttentionFn.apply(q, k, v, num_heads, mask, drop)
+    ctx = _AttentionFn.apply(q, k, v, num_heads, mask, drop, causal)
     return linear(ctx, out_w, out_b)
 
 
@@ -239,11 +239,12 @@ def dropout(x, p, training):
 
 class _CEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, label_smoothing):
         B, Cn = logits.shape
         lg = logits.contiguous().float()
-        loss, pred, lse, nvalid = K.ce_argmax_fwd(lg, labels, B, Cn)
+        loss, pred, lse, nvalid = K.ce_argmax_fwd(lg, labels, B, Cn, label_smoothing)
         ctx.save_for_backward(lg, labels, lse, nvalid)
+        ctx.smooth = label_smoothing
         ctx.mark_non_differentiable(pred)
         return loss, pred
 
@@ -251,11 +252,11 @@ class _CEFn(torch.autograd.Function):
     def backward(ctx, dloss, _dpred):
         lg, labels, lse, nvalid = ctx.saved_tensors
         B, Cn = lg.shape
-        dl, _ = K.ce_bwd(lg, labels, lse, dloss.contiguous().float(), B, Cn, nvalid=nvalid)
-        return dl, None
+        dl, _ = K.ce_bwd(lg, labels, lse, dloss.contiguous().float(), B, Cn, nvalid=nvalid, label_smoothing=ctx.smooth)
+        return dl, None, None
 
 
-def cross_entropy_argmax(logits, labels):
+def cross_entropy_argmax(logits, labels, label_smoothing: float = 0.0):
     """(mean CE loss, argmax ids) in one pass over the logits (reference vqa_model.py:711-716: ``F.cross_entropy`` defaults,
     i.e. ``ignore_index=-100`` rows are skipped and not counted by the mean).  Labels are validated on the host for what costs no
     sync (rank, device, integer dtype -- int32 from a collator is widened, a float tensor is an error as in torch); their RANGE is
@@ -268,7 +269,7 @@ def cross_entropy_argmax(logits, labels):
         raise RuntimeError(f'cross_entropy_argmax: labels on {labels.device}, logits on {logits.device}')
     if labels.dtype.is_floating_point or labels.dtype == torch.bool:
         raise RuntimeError(f'cross_entropy_argmax: labels must be an integer tensor of class indices (got {labels.dtype})')
-    return _CEFn.apply(logits, labels.long().contiguous())
+    return _CEFn.apply(logits, labels.long().contiguous(), float(label_smoothing))
 
 
 def argmax(logits):

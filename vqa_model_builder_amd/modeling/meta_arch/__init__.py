@@ -17,10 +17,12 @@ _GENERATIVE = ('GenerativeVQAConfig', 'GenerativeVQAOutput', 'GenerativeVQAModel
 
 
 def __getattr__(name):
-    """The generative names of the reference's ``src.modeling.meta_arch`` (meta_arch/__init__.py:39-71): not re-implemented on the HIP
-    path.  ``vqa_model_builder_amd.install_as_src()`` binds them to the reference's own implementation
-    when the reference tree is importable; without it, asking for one fails loudly instead of resolving to nothing."""
+    """The generative names of the reference's ``src.modeling.meta_arch`` (meta_arch/__init__.py:39-71) resolve -- lazily, so the
+    classification path never imports it -- to this package's HIP implementation (generative_vqa_model.py: started this round;
+    default configuration and the fusion-MoE variants, not ``moe_type='sparse'``).  ``vqa_model_builder_amd.install_as_src()``
+    keeps binding the reference's OWN generative module under ``src.modeling.meta_arch`` when the reference tree is importable
+    (``install_as_src(generative='hip')`` binds this one)."""
     if name in _GENERATIVE:
-        raise ImportError(f'{name}: the generative VQA path is not part of this build; put the reference tree on sys.path and call '
-                          'vqa_model_builder_amd.install_as_src() to use its own implementation alongside the HIP classification model')
+        from . import generative_vqa_model as g
+        return getattr(g, name)
     raise AttributeError(name)
