@@ -338,9 +338,11 @@ class TransformerDecoder(nn.Module):
         B, A = decoder_input_ids.shape
         V, D = self.embedding.weight.shape
         ids = decoder_input_ids.reshape(-1)
-        if not bool(((ids >= 0) & (ids < V)).all()):            # nn.Embedding device-asserts; generation is host-driven anyway
-            raise IndexError('TransformerDecoder: decoder_input_ids out of range')
-        x = _EmbeddingFn.apply(self.embedding.weight, ids.to(torch.int32).contiguous()).view(B, A, D)
+        # nn.Embedding device-asserts on an id outside [0, V); here such an id is never dereferenced (clamped) and clears the device
+        # status word that ``hip.kernels.check_device_status`` reads -- no host sync on the path, so the step can be captured
+        ok = ((ids >= 0) & (ids < V)).all()
+        K.status_word(ids.device).mul_(ok.to(torch.int32))
+        x = _EmbeddingFn.apply(self.embedding.weight, ids.clamp(0, V - 1).to(torch.int32).contiguous()).view(B, A, D)
         x = self.pos_encoding(x)
         mem_kpm = (encoder_attention_mask == 0) if encoder_attention_mask is not None else None
         tgt_kpm = (decoder_attention_mask == 0) if decoder_attention_mask is not None else None
