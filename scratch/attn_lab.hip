@@ -17,8 +17,8 @@
 namespace {
 
 struct MArgs {
-    const bf16_t *q, *k, *v, *d_o;
-    bf16_t *o, *dq, *dk, *dv;
+    const h16_t *q, *k, *v, *d_o;
+    h16_t *o, *dq, *dk, *dv;
     int ldq, ldk, ldv, ldo, ldd_o, lddq, lddk, lddv;
     int B, H, Sq, Skv;
     const uint8_t* mask;
@@ -32,7 +32,7 @@ struct MArgs {
 // fold the 16 row-lanes; lanes i == 0 leave their 4 columns in the wave's LDS row.  The workgroup's four rows are summed
 // at the end and added to the accumulator ONCE per workgroup: B adders per address (one per batch element), inside the
 // range where float atomics keep their rate (per-wave adds -- 4 B adders -- ran the kernel 2.4x slower).
-__device__ __forceinline__ void slab_colsum(float* lds_row, const bf16x4& v, bool row_ok, int lane) {
+__device__ __forceinline__ void slab_colsum(float* lds_row, const h16x4& v, bool row_ok, int lane) {
     f32x4 c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) c[r] = row_ok ? (float)v[r] : 0.f;
@@ -45,7 +45,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int PT = 144;          // pitch of the [kv][q] P^T / dS^T tiles (64 bf16 + 16 B)
 
 template <int DH>
-__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* g, int rows, int ld, int tid) {
+__device__ __forceinline__ void stage_tile(char* lds, const h16_t* g, int rows, int ld, int tid) {
     constexpr int PITCH = DH * 2 + 16, CPR = DH / 8;          // 16-B chunks per row
     for (int c = tid; c < 64 * CPR; c += 256) {
         const int r = c / CPR, cc = c % CPR;
@@ -56,25 +56,25 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* g, int rows,
 }
 
 // row fragment: 16 rows r0.., 8 consecutive k at k0 + 8*(lane>>4)
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int pitch, int r0, int k0, int lane) {
-    return *reinterpret_cast<const bf16x8*>(tile + (r0 + (lane & 15)) * pitch + (k0 + 8 * (lane >> 4)) * 2);
+__device__ __forceinline__ h16x8 row_frag(const char* tile, int pitch, int r0, int k0, int lane) {
+    return *reinterpret_cast<const h16x8*>(tile + (r0 + (lane & 15)) * pitch + (k0 + 8 * (lane >> 4)) * 2);
 }
 // column fragment through the transposing read: lane gets column c0 + (lane&15); its 8 k-slots are tile rows
 // ra(g)+0..3 and rb(g)+0..3 where g = lane>>4 (the caller chooses the k order)
-__device__ __forceinline__ bf16x8 col_frag(const char* tile, int pitch, int ra, int rb, int c0, int lane) {
+__device__ __forceinline__ h16x8 col_frag(const char* tile, int pitch, int ra, int rb, int c0, int lane) {
     const int i = lane & 15;
     const int off = (i >> 2) * pitch + (c0 + 4 * (i & 3)) * 2;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + ra * pitch + off));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + rb * pitch + off));
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    union { struct { s16x4 a, b; } s; h16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
 }
 
-__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-    bf16x8 r;
+__device__ __forceinline__ h16x8 pack8(const f32x4& a, const f32x4& b) {
+    h16x8 r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { r[j] = (bf16_t)a[j]; r[4 + j] = (bf16_t)b[j]; }
+    for (int j = 0; j < 4; ++j) { r[j] = (h16_t)a[j]; r[4 + j] = (h16_t)b[j]; }
     return r;
 }
 
@@ -90,7 +90,7 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
     for (int t = 0; t < 4; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < DH / 32; ++kk) {
-        const bf16x8 qf = row_frag(Qs, PITCH, 16 * w, 32 * kk, lane);
+        const h16x8 qf = row_frag(Qs, PITCH, 16 * w, 32 * kk, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, PITCH, 16 * t, 32 * kk, lane), qf, s[t], 0, 0, 0);
     }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MArgs a_in) {
     if (16 * w >= a.Sq) return;                      // whole wave beyond the last query row (no barrier follows)
     f32x4 pn[4], ks[4];
     scores_softmax<DH>(a, Qs, Ks, b, h, w, lane, pn, ks);
-    bf16x8 pf[2];
+    h16x8 pf[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) pf[u] = pack8(pn[2 * u] * ks[2 * u], pn[2 * u + 1] * ks[2 * u + 1]);
     const int q = 16 * w + (lane & 15);
@@ -167,10 +167,10 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MArgs a_in) {
         for (int u = 0; u < 2; ++u)
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Vs, PITCH, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, lane), pf[u], o, 0, 0, 0);
         if (q < a.Sq) {
-            bf16x4 ob;
+            h16x4 ob;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)o[r];
-            *reinterpret_cast<bf16x4*>(a.o + ((size_t)b * a.Sq + q) * a.ldo + h * DH + 16 * dt + 4 * g) = ob;
+            for (int r = 0; r < 4; ++r) ob[r] = (h16_t)o[r];
+            *reinterpret_cast<h16x4*>(a.o + ((size_t)b * a.Sq + q) * a.ldo + h * DH + 16 * dt + 4 * g) = ob;
         }
     }
 }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
         for (int t = 0; t < 4; ++t) dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < DH / 32; ++kk) {
-            const bf16x8 gf = row_frag(Gs, PITCH, 16 * w, 32 * kk, lane);
+            const h16x8 gf = row_frag(Gs, PITCH, 16 * w, 32 * kk, lane);
 #pragma unroll
             for (int t = 0; t < 4; ++t) dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, PITCH, 16 * t, 32 * kk, lane), gf, dp[t], 0, 0, 0);
         }
@@ -223,11 +223,11 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
                 const float pd = qok ? pn[t][r] * ks[t][r] : 0.f;
                 dp[t][r] = ds;                                         // dp now holds dS^T
                 const int kv = 16 * t + 4 * g + r;
-                *reinterpret_cast<bf16_t*>(Pt + kv * PT + q * 2) = (bf16_t)pd;
-                *reinterpret_cast<bf16_t*>(Dt + kv * PT + q * 2) = (bf16_t)ds;
+                *reinterpret_cast<h16_t*>(Pt + kv * PT + q * 2) = (h16_t)pd;
+                *reinterpret_cast<h16_t*>(Dt + kv * PT + q * 2) = (h16_t)ds;
             }
         // dQ^T = K^T dS^T, dS^T straight from the accumulator registers
-        bf16x8 df[2];
+        h16x8 df[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) df[u] = pack8(dp[2 * u], dp[2 * u + 1]);
 #pragma unroll 1
@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Ks, PITCH, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, lane), df[u], o, 0, 0, 0);
-            bf16x4 ob;
+            h16x4 ob;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)o[r];
-            if (qok) *reinterpret_cast<bf16x4*>(a.dq + ((size_t)b * a.Sq + q) * a.lddq + h * DH + 16 * dt + 4 * g) = ob;
+            for (int r = 0; r < 4; ++r) ob[r] = (h16_t)o[r];
+            if (qok) *reinterpret_cast<h16x4*>(a.dq + ((size_t)b * a.Sq + q) * a.lddq + h * DH + 16 * dt + 4 * g) = ob;
             if (want_cs) slab_colsum(&cs_part[0][w][16 * dt + 4 * g], ob, qok, lane);
         }
     }
@@ -256,17 +256,17 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
         f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bf16x8 pf = row_frag(Pt, PT, 16 * w, 32 * u, lane);
-            const bf16x8 sf = row_frag(Dt, PT, 16 * w, 32 * u, lane);
+            const h16x8 pf = row_frag(Pt, PT, 16 * w, 32 * u, lane);
+            const h16x8 sf = row_frag(Dt, PT, 16 * w, 32 * u, lane);
             ov = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Gs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), pf, ov, 0, 0, 0);
             ok = __builtin_amdgcn_mfma_f32_16x16x32_bf16(col_frag(Qs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), sf, ok, 0, 0, 0);
         }
-        bf16x4 bv, bk;
+        h16x4 bv, bk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { bv[r] = (bf16_t)ov[r]; bk[r] = (bf16_t)ok[r]; }
+        for (int r = 0; r < 4; ++r) { bv[r] = (h16_t)ov[r]; bk[r] = (h16_t)ok[r]; }
         if (kok) {
-            *reinterpret_cast<bf16x4*>(a.dv + ((size_t)b * a.Skv + kv) * a.lddv + h * DH + 16 * dt + 4 * g) = bv;
-            *reinterpret_cast<bf16x4*>(a.dk + ((size_t)b * a.Skv + kv) * a.lddk + h * DH + 16 * dt + 4 * g) = bk;
+            *reinterpret_cast<h16x4*>(a.dv + ((size_t)b * a.Skv + kv) * a.lddv + h * DH + 16 * dt + 4 * g) = bv;
+            *reinterpret_cast<h16x4*>(a.dk + ((size_t)b * a.Skv + kv) * a.lddk + h * DH + 16 * dt + 4 * g) = bk;
         }
         if (want_cs) {
             slab_colsum(&cs_part[1][w][16 * dt + 4 * g], bk, kok, lane);
@@ -295,8 +295,8 @@ bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
     if (!bwd && ((uintptr_t)d->o & 7)) return false;
     if (bwd && ((d->ldd_o | d->lddq | d->lddk | d->lddv) % 8 || ((uintptr_t)d->d_o & 15) || (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7)))
         return false;
-    a.q = (const bf16_t*)d->q; a.k = (const bf16_t*)d->k; a.v = (const bf16_t*)d->v; a.o = (bf16_t*)d->o;
-    a.d_o = (const bf16_t*)d->d_o; a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
+    a.q = (const h16_t*)d->q; a.k = (const h16_t*)d->k; a.v = (const h16_t*)d->v; a.o = (h16_t*)d->o;
+    a.d_o = (const h16_t*)d->d_o; a.dq = (h16_t*)d->dq; a.dk = (h16_t*)d->dk; a.dv = (h16_t*)d->dv;
     a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo; a.ldd_o = d->ldd_o; a.lddq = d->lddq; a.lddk = d->lddk; a.lddv = d->lddv;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Skv = d->Skv;
     a.mask = d->key_padding_mask;
