@@ -634,16 +634,24 @@ struct GroupArgs { int n; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
-    const int t = xcd_remap(blockIdx.x, g.tile_end[g.n - 1]);
+    // PERSISTENT when the host launched fewer workgroups than tiles (vqa_set_gemm_group_persistent): workgroup b walks tiles
+    // b, b + G, b + 2G ...: the ~2 us of ramp every workgroup pays (kernel arguments, cold instruction cache) is paid once per
+    // workgroup instead of once per tile -- it matters for the experts' weight gradients, whose reduction is only 32 - 128 tokens long
+    const int total = g.tile_end[g.n - 1];
     int i = 0;
-    while (i + 1 < g.n && t >= g.tile_end[i]) ++i;
-    const GroupItem& it = g.it[i];
-    GemmArgs p{};
-    p.a = it.a; p.b = it.b; p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb;
-    p.c_f32 = it.c; p.ldc_f32 = it.ldc;
-    p.alpha = 1.f; p.drop_inv_keep = 1.f; p.tiles_n = it.tiles_n; p.tiles_n_magic = it.tiles_n_magic;
-    p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
-    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
+    for (int tt = blockIdx.x; tt < total; tt += gridDim.x) {
+        const int t = xcd_remap(tt, total);
+        if (t < (i ? g.tile_end[i - 1] : 0)) i = 0;
+        while (i + 1 < g.n && t >= g.tile_end[i]) ++i;
+        const GroupItem& it = g.it[i];
+        GemmArgs p{};
+        p.a = it.a; p.b = it.b; p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb;
+        p.c_f32 = it.c; p.ldc_f32 = it.ldc;
+        p.alpha = 1.f; p.drop_inv_keep = 1.f; p.tiles_n = it.tiles_n; p.tiles_n_magic = it.tiles_n_magic;
+        p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
+        gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
+        __syncthreads();                                     // the ring (epilogue scratch) is free again
+    }
 }
 
 // ================================================================================================================
@@ -1132,6 +1140,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
         default: return launch_cfg<64, 128, 2, 2>(p, d->a_kc, d->b_kc, splits, stream);
     }
 }
+int g_group_persistent = 0; // > 0: grouped launches run persistent on at most this many workgroups (vqa_set_gemm_group_persistent)
 template <int BM, int BN, int ST, bool AK, bool BKC>
 static int launch_grouped(const GroupArgs& g, hipStream_t st) {
     constexpr int LDS = ST * (BM + BN) * 64 * 2;
@@ -1144,12 +1153,15 @@ static int launch_grouped(const GroupArgs& g, hipStream_t st) {
     }
     double flop = 0.0;
     for (int i = 0; i < g.n; ++i) flop += 2.0 * g.it[i].M * g.it[i].N * g.it[i].K;
-    vqa_launch(kern, dim3(g.tile_end[g.n - 1]), dim3(256), LDS, st, g, flop);
+    int grid = g.tile_end[g.n - 1];
+    if (g_group_persistent > 0 && grid > g_group_persistent) grid = g_group_persistent / 8 * 8;      // a multiple of 8: the XCD remap stays a bijection
+    vqa_launch(kern, dim3(grid), dim3(256), LDS, st, g, flop);
     return (int)hipGetLastError();
 }
 
 int g_group_tile = 0;      // 0: heuristic; 1: 64x64; 2: 128x64; 3: 128x128 (diagnostics: vqa_set_gemm_group_tile)
 extern "C" void vqa_set_gemm_group_tile(int t) { g_group_tile = t; }
+extern "C" void vqa_set_gemm_group_persistent(int n) { g_group_persistent = n; }
 
 extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t stream_) {
     if (!items || n <= 0 || n > MAX_GROUP) return VQA_ERR_ARG;

@@ -105,6 +105,7 @@ SIGNATURES = {
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
     'vqa_gemm_bf16_grouped': (i32, [vp, i32, i32, i32, vp]),
     'vqa_set_gemm_group_tile': (None, [i32]),
+    'vqa_set_gemm_group_persistent': (None, [i32]),
     'vqa_set_gemm_grid_cap': (None, [i32]),
     'vqa_set_gemm_force': (None, [i32, i32]),
     'vqa_layernorm_bwd_blocks': (i32, [i32]),
