@@ -35,4 +35,4 @@ for tag in ('pmc_fetch', 'pmc_write', 'pmc_mfma'):
         w = csv.writer(fo); w.writerow(['kernel', 'counter', 'value', 'grid', 'workgroup']); w.writerows(rows)
     print(tag, len(rows), 'rows')
 PY
-for k in graph eager cfg3; do grep "^{" $out/$k.log | tail -1 > $R/profiles/$rnd/${k}_bench_line.json; cp $out/${k}_kernel_stats.csv $R/profiles/$rnd/; done; cp $out/pmc_*_gemm_rows.csv $R/profiles/$rnd/
+echo "copy gpurun_out/prof_$rnd/{*_kernel_stats.csv,pmc_*_gemm_rows.csv,gemm_traffic.json} into profiles/$rnd/ (only gpurun_out/ travels back from the GPU box)"
