@@ -319,6 +319,119 @@ def test_fused_inproj_attention_rejects_uncovered_shapes():
         K.fused_inproj_attention_fwd(x, x, w, None, B, H, S, S, D)
 
 
+@pytest.mark.parametrize('B,H,Sq,Skv,Dh', [(3, 4, 16, 16, 32), (2, 8, 33, 33, 96), (2, 2, 100, 100, 64)])
+def test_causal_attention_fwd_bwd(B, H, Sq, Skv, Dh):
+    """``causal`` (nn.TransformerDecoder's tgt_mask, generative_vqa_model.py:447-451) in the MFMA and the generic kernel, with a key
+    padding mask on top: against torch's masked softmax, forward and the three gradients."""
+    D = H * Dh
+    q, k, v = [rnd((B * s, D), i).to(DEV).to(BF) for i, s in ((1, Sq), (2, Skv), (3, Skv))]
+    mask = torch.zeros((B, Skv), dtype=torch.uint8, device=DEV)
+    mask[0, Skv - 3:] = 1                                    # trailing pads: every query still sees key 0
+    o = K.attention_fwd(q, k, v, D, D, D, B, H, Sq, Skv, Dh, mask, causal=True)
+    qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+    qh, kh, vh = [t.view(B, -1, H, Dh).transpose(1, 2) for t in (qf, kf, vf)]
+    sc = qh @ kh.transpose(-1, -2) * Dh ** -0.5
+    sc = sc + torch.triu(torch.full((Sq, Skv), float('-inf'), device=DEV), diagonal=1)
+    sc = sc.masked_fill(mask[:, None, None, :].bool(), float('-inf'))
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B * Sq, D)
+    assert torch.allclose(o.float(), ref, atol=2e-2, rtol=2e-2)
+    do = rnd((B * Sq, D), 4).to(DEV).to(BF)
+    ref.backward(do.float())
+    dq, dk, dv = [torch.empty((B * s, D), dtype=BF, device=DEV) for s in (Sq, Skv, Skv)]
+    K.attention_bwd(q, k, v, do, D, D, D, B, H, Sq, Skv, Dh, dq, dk, dv, D, D, D, mask, causal=True)
+    for got, want in ((dq, qf.grad), (dk, kf.grad), (dv, vf.grad)):
+        assert (got.float() - want).abs().max().item() / (want.abs().max().item() + 1e-6) < 2e-2
+    if Sq <= 64 and Dh in (64, 96) and (H * Dh) % 64 == 0:     # and through the fused in-projection kernel
+        x = rnd((B * Sq, D), 5).to(DEV).to(BF)
+        w = (rnd((3 * D, D), 6) * D ** -0.5).to(DEV).to(BF)
+        _, qkv, _ = K.linear_fwd(x, w, None, B * Sq, 3 * D, D, want_bf16=True)
+        o2 = K.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D, B, H, Sq, Sq, Dh, mask, causal=True)
+        assert torch.equal(K.fused_inproj_attention_fwd(x, x, w, None, B, H, Sq, Sq, D, mask, causal=True), o2)
+
+
+def test_cross_entropy_label_smoothing_matches_torch():
+    """nn.CrossEntropyLoss(ignore_index=-100, label_smoothing=0.1) (generative_vqa_model.py:507-510): loss and logits gradient, wide
+    vocabulary, ignored rows."""
+    B, C = 37, 6400
+    logits = (rnd((B, C), 1) * 3).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    labels[5] = labels[20] = -100
+    ref = torch.nn.functional.cross_entropy(logits, labels, ignore_index=-100, label_smoothing=0.1)
+    ref.backward()
+    loss, pred, lse, nvalid = K.ce_argmax_fwd(logits.detach(), labels, B, C, label_smoothing=0.1)
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref) and float(nvalid) == B - 2
+    assert torch.equal(pred, logits.detach().argmax(-1))
+    dl, _ = K.ce_bwd(logits.detach(), labels, lse, torch.tensor(1.0, device=DEV), B, C, nvalid=nvalid, label_smoothing=0.1)
+    assert torch.allclose(dl, logits.grad, atol=1e-7, rtol=1e-4)
+
+
+def test_expert_row_kernels_against_torch():
+    """csrc/expert_ops.hip one by one: mask * act' * cast + column sums, attention over ONE key (keep-scale per (sample, head,
+    query), forward broadcast and backward reduction consistent with each other and with the attention kernel's key), row repeat /
+    tile, group mean, strided take / scatter (Conv1d centre tap), dense MoE combine forward / backward, embedding backward."""
+    M, N = 70, 256
+    dy, pre = rnd((M, N), 1).to(DEV), rnd((M, N), 2).to(DEV).to(BF)
+    cs = torch.zeros(N, device=DEV)
+    out = K.rows_mask_cast(dy, M, N, pre=pre, act=K.ACT_GELU, colsum=cs)
+    pf = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(pf).backward(dy)
+    assert torch.allclose(out.float(), pf.grad, atol=2e-2, rtol=2e-2)
+    assert torch.allclose(cs, out.float().sum(0), atol=1e-3, rtol=1e-4)
+    d = K.Drop(0.3, 77, 9)
+    o1, o2 = K.rows_mask_cast(dy, M, N, drop=d), K.rows_mask_cast(dy, M, N, drop=d)
+    keep = (o1.float() != 0).float().mean().item()
+    assert torch.equal(o1, o2) and abs(keep - 0.7) < 0.03
+    yb = torch.empty((M, N), dtype=BF, device=DEV)                    # the same mask as the GEMM epilogue that applied it in forward
+    eye = torch.eye(N, device=DEV).to(BF)
+    K.gemm(dy.to(BF), eye, M, N, N, N, N, True, True, out_bf16=yb, drop=d)
+    assert torch.equal(yb == 0, K.rows_mask_cast(dy.to(BF).float(), M, N, drop=d) == 0)
+    # one-key attention
+    T, R, H, Dh = 6, 4, 8, 32
+    v = rnd((T, H * Dh), 3).to(DEV).to(BF)
+    assert torch.equal(K.head_keep_fwd(v, T, R, H, Dh), v.repeat_interleave(R, 0))
+    dr = K.Drop(0.25, 5, 3)
+    f = K.head_keep_fwd(v, T, R, H, Dh, dr)
+    ratio = (f.float() / v.repeat_interleave(R, 0).float()).view(T * R, H, Dh)
+    assert torch.allclose(ratio, ratio[:, :, :1].expand_as(ratio), atol=2e-2)          # one scale per (row, head)
+    r0 = ratio[:, :, 0]
+    assert bool(((r0 == 0) | ((r0 - 1 / 0.75).abs() < 0.03)).all()) and 0.5 < float((r0 != 0).float().mean()) < 0.95
+    q = torch.zeros((T * R, H * Dh), dtype=BF, device=DEV)
+    att = K.attention_fwd(q, v, v, H * Dh, H * Dh, H * Dh, T, H, R, 1, Dh, None, dr)           # the attention kernel over one key: same keep pattern
+    assert torch.equal(att == 0, f == 0)
+    g = rnd((T * R, H * Dh), 4).to(DEV).to(BF)
+    want = (g.float() * ratio.reshape(T * R, -1).nan_to_num(0.0)).view(T, R, -1).sum(1)
+    assert torch.allclose(K.head_keep_bwd(g, T, R, H, Dh, dr).float(), want, atol=3e-2, rtol=3e-2)
+    # repeat / tile / mean / strides
+    src = rnd((5, 64), 5).to(DEV)
+    a, ab = K.repeat_rows(src, 15, 64, 3, 0, alpha=0.5, want_bf16=True)
+    assert torch.equal(a, src.repeat_interleave(3, 0) * 0.5) and torch.equal(ab, a.to(BF))
+    assert torch.equal(K.repeat_rows(src, 15, 64, 5, 1)[0], src.repeat(3, 1))
+    mb = torch.zeros((5, 128), dtype=BF, device=DEV)
+    K.rows_mean(a, 3, 5, 64, out_bf16=mb[:, 64:], ld_out=128)
+    assert torch.allclose(mb[:, 64:].float(), (src * 0.5), atol=1e-2) and float(mb[:, :64].abs().max()) == 0.0
+    w3 = rnd((16, 16, 3), 6).to(DEV)
+    assert torch.equal(K.take_stride(w3.to(BF).reshape(-1), 256, 3, 1).view(16, 16), w3.to(BF)[:, :, 1])
+    gz = torch.zeros_like(w3)
+    K.scatter_stride(w3[:, :, 1].contiguous(), gz, 256, 3, 1)
+    assert torch.equal(gz[:, :, 1], w3[:, :, 1]) and float(gz[:, :, 0].abs().max()) == 0.0 and float(gz[:, :, 2].abs().max()) == 0.0
+    # dense combine
+    Tt, E, D = 9, 4, 64
+    ys = [rnd((Tt, D), 10 + e).to(DEV).requires_grad_(True) for e in range(E)]
+    w = rnd((E, Tt), 20).to(DEV).requires_grad_(True)
+    ref = sum(w[e][:, None] * ys[e] for e in range(E))
+    go = rnd((Tt, D), 30).to(DEV)
+    ref.backward(go)
+    assert torch.allclose(K.moe_dense_combine_fwd([y.detach() for y in ys], w.detach(), Tt, E, D), ref, atol=1e-5)
+    dys, dw = K.moe_dense_combine_bwd(go, [y.detach() for y in ys], w.detach(), Tt, E, D)
+    assert torch.allclose(dw, w.grad, atol=1e-4) and all(torch.allclose(a_, y.grad, atol=1e-6) for a_, y in zip(dys, ys))
+    # embedding backward with repeated ids
+    ids = torch.tensor([0, 3, 0, 7, 3, 0], dtype=torch.int32, device=DEV)
+    gy = rnd((6, 32), 40).to(DEV)
+    dwt = torch.zeros((9, 32), device=DEV)
+    K._chk(K.L().vqa_embedding_rows_bwd(gy.data_ptr(), ids.data_ptr(), dwt.data_ptr(), 6, 32, 9, K._stream()), 'vqa_embedding_rows_bwd')
+    assert torch.allclose(dwt, torch.zeros((9, 32), device=DEV).index_add_(0, ids.long(), gy), atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ front ends
 def test_patchify_and_clip_assemble():
     B, Cc, H, W, ps, D = 3, 3, 64, 96, 16, 32
