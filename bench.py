@@ -383,7 +383,7 @@ def main():
                                'bytes_per_step': byts, 'traffic': None,
                                'note': 'whole step against the batch-independent parameter traffic (4 + 4 + 30 B/param); activations excluded'}
 
-    # Data-parallel readiness, measured on ONE GPU: the five-graph segmented step (what N > 1 runs) without an exchange gives the
+    # Data-parallel readiness, measured on ONE GPU: the segmented step (what N > 1 runs: one graph per block) without an exchange gives the
     # compute side of an N-GPU step; the exchange of the last block (the only exposed one) is modelled from its byte count.
     dp_model = None
     if world == 1 and not args.no_second_workload and not args.eager and not args.torch_optimizer:
@@ -408,7 +408,7 @@ def main():
                 return {'exposed_allreduce_ms': round(exposed, 3), 'ms_per_step': round(step, 3), 'scaling_vs_1gpu': round(8 * main_res['ms_per_step'] / step, 2)}
             dp_model = {'segmented_step_ms_1gpu': total, 'segment_ms_1gpu': sm, 'optimizer_ms': round(t_opt, 3), 'segment_bytes_fp32': sb,
                         'assumed_bus_GBps': BUS / 1e9, 'predicted_8gpu_fp32_buckets': predict(1.0), 'predicted_8gpu_bf16_buckets': predict(0.5),
-                        'note': 'compute = the five graphs of the segmented step measured on one GPU (no exchange); exchange = ring all-reduce of each '
+                        'note': 'compute = the graphs of the segmented step measured on one GPU (no exchange); exchange = ring all-reduce of each '
                                 'block behind one RCCL stream, started when the block\'s graph is done; the xGMI bus bandwidth is an ASSUMPTION, not '
                                 'a measurement -- the driver\'s N = 8 run is the measurement'}
         except Exception as e:                       # noqa: BLE001

@@ -150,7 +150,7 @@ def test_graphed_data_parallel_step_matches_eager_data_parallel_step(mode, tol):
 
 
 def test_segmented_data_parallel_step_with_moe_dense_dispatch():
-    """MoE-4 under the five-graph step: dense dispatch inside the captures, routed-token counts all-reduced so an expert is
+    """MoE-4 under the multi-graph captured step: dense dispatch inside the captures, routed-token counts all-reduced so an expert is
     updated when ANY rank routed to it; against the eager step (sparse dispatch, grad-is-None skipping)."""
     eager, graph = _run_two('eager_moe'), _run_two('graph_moe')
     assert graph[0][2]['segmented']

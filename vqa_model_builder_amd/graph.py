@@ -18,19 +18,21 @@ expert no token chose is skipped by the optimiser through a device-side routed-t
 ONE GPU: one graph for the whole step (two parallel encoder branches, all weight-gradient GEMMs grouped at the end).
 
 DATA PARALLEL (a ``dp.GradReducer`` is given): collectives stay outside captures, so the step is cut where the gradient
-exchange can start -- the autograd graph is severed at the encoder outputs and the step becomes FIVE graphs
+exchange can start -- the autograd graph is severed at the encoder outputs and the step becomes SEVEN graphs
 
-    F  both encoders forward (parallel branches)
-    H  fusion + MoE + answer head forward AND backward  -> gradients of the head / fusion / MoE and of the encoder outputs
-    T  text-encoder backward                              (the larger arena: 135 M parameters)
-    V  vision-encoder backward
-    O  clip + AdamW (+ loss-scale update)
+    F       both encoders forward (parallel branches)
+    H       fusion + MoE + answer head forward AND backward  -> gradients of the head / fusion / MoE and of the encoder outputs
+    T, T2   text-encoder backward: upper half of the layers | lower half + embeddings   (resumable runner backward: blocks.py)
+    V, V2   vision-encoder backward, likewise
+    O       clip + AdamW (+ loss-scale update)
 
-and the host replays  F, H, [all-reduce H's arenas], T, [all-reduce T's arena], V, [all-reduce V's arena], wait, O:  every
-``all_reduce`` is asynchronous on RCCL's own stream, ordered after the graph that produced its gradients and running beside
-the next graph, so only the LAST block's exchange (the vision arena, 350 MB fp32 / 175 MB with bf16 buckets) is exposed --
-round 1 exposed all 0.98 GB between one backward graph and the optimiser graph.  ``comm_stats()`` reports the measured
-exposed time; tests/test_dp_gpu.py checks the segmented step against the eager data-parallel step.
+and the host replays  F, H, [all-reduce H], T, [all-reduce T], T2, [...], V, [...], V2, [all-reduce V2], wait, O:  every
+``all_reduce`` is asynchronous on RCCL's own stream, IN PLACE on the contiguous runs of the segment's gradients inside the block's
+arena, ordered after the graph that produced them and running beside the next graph, so only the LAST half-block's exchange (180 MB
+fp32 / 90 MB with bf16 buckets) is exposed -- round 1 exposed all 0.98 GB between one backward graph and the optimiser graph.
+``comm_stats()`` reports the measured exposed time and the GPU time of every graph; tests/test_dp_gpu.py checks the captured step
+against the eager data-parallel step.  Forks inside a capture are ONE level deep (a fork nested in a forked branch faults in this
+runtime: profiles/r02/nested_fork_capture.md).
 """
 
 from typing import Callable, Dict, Optional
@@ -56,7 +58,7 @@ class GraphedTrainStep:
         ``split_encoders`` (segmented step): each encoder's backward as two graphs (upper / lower half of its layers).
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
-        ``forward_from_features``): the five-graph data-parallel step described in the module docstring."""
+        ``forward_from_features``): the multi-graph data-parallel step described in the module docstring."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.loss_of = loss_of or (lambda out: out.loss)
         self.static = {k: v.clone() for k, v in batch.items()}
