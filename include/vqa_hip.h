@@ -272,6 +272,9 @@ int vqa_moe_dense_combine_bwd(const float* dout, const float* const* ys, const f
  * backward of y = drop(act(pre)) + the bias gradient of the Linear that produced pre, in one pass (M small). */
 int vqa_rows_mask_cast(const float* dy, int ld, const void* pre_bf16, int act, void* out_bf16, float* colsum, int M, int N, float p,
                        uint64_t seed, uint32_t stream, vqa_stream_t s);
+/* y = dropout(act(x)) where the activation does not ride in a GEMM epilogue (fusion_approaches.py:124-131: Linear -> LayerNorm -> GELU ->
+ * Dropout); optional 16-bit copies of y and of x (what vqa_act_drop_bwd reads as the pre-activation); dropout keyed by element index */
+int vqa_act_drop_fwd(const float* x, float* y, void* y_bf16, void* pre_bf16, size_t n, int act, float p, uint64_t seed, uint32_t stream, vqa_stream_t s);
 /* nn.MultiheadAttention over ONE key per sample: softmax == 1, the context is V times the dropout keep-scale of the (sample, head,
  * query) probability.  fwd: out[(t*R + r), :] = v[t, :] * keep(t, head, r)  (R queries per sample; p == 0: a plain broadcast);
  * bwd: dv[t, :] = sum_r dout[(t*R + r), :] * keep(t, head, r).  bf16 in / out, keyed like vqa_attention_fwd's element (b, h, q, 0). */

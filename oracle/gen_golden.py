@@ -1,7 +1,7 @@
 """Golden-vector generator.  Runs ONLY in the build container, where /root/reference is importable.
 
     mkdir -p /tmp/golden_cwd && cd /tmp/golden_cwd && \
-    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts|generative]
+    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts|generative|fusion]
 
 It imports the reference's own ``src.modeling.meta_arch`` / ``src.modeling.moe`` modules (SURVEY.md
 §8c, Appendix C), replaces only the two hub-NAME loaders by local random-weight construction of the
@@ -486,6 +486,52 @@ def run_generative_case(tag, dims, seed, full_logits):
           f'({os.path.getsize(path) / 1e3:.0f} kB)')
 
 
+FUSION_CASES = {
+    'fusion_xattn_tiny': dict(B=3, V=5, T=8, vision_dim=48, text_dim=64, output_dim=64, num_attention_heads=4, num_layers=2, intermediate_dim=96,
+                              fusion_method='concat'),
+    'fusion_xattn_full': dict(B=4, V=50, T=64, vision_dim=768, text_dim=768, output_dim=768, num_attention_heads=8, num_layers=4,
+                              intermediate_dim=3072, fusion_method='add'),
+}
+
+
+def run_fusion_case(tag, case, seed):
+    """The reference's stand-alone ``CrossAttentionFusion`` (fusion_approaches.py:59-281): eval forward + backward of <out, gy>."""
+    from src.modeling.fusion.fusion_approaches import CrossAttentionFusion
+    from oracle import gen_oracle as go
+    kw = {k: case[k] for k in ('vision_dim', 'text_dim', 'output_dim', 'num_attention_heads', 'num_layers', 'intermediate_dim', 'fusion_method')}
+    model = CrossAttentionFusion(dropout=0.1, **kw).eval()
+    shapes = dw.shapes_of(model.state_dict())
+    sd = dw.make_state_dict(shapes, seed)
+    model.load_state_dict(sd)
+    meta = dict(tag=tag, case=case, seed=seed, shapes={k: list(v) for k, v in shapes.items()}, keys=list(shapes), weights_checksum=dw.checksum(sd))
+    v, t, vmask, tmask, gy = go.fusion_fixture_inputs(meta)
+    v.requires_grad_(True); t.requires_grad_(True)
+    with torch.enable_grad():
+        out = model(v, t, vmask, tmask)
+        (out * gy).sum().backward()
+    arrays = {'out': out.detach().numpy(), 'dv': v.grad.numpy(), 'dt': t.grad.numpy()}
+    out0, grads0 = out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    for n, g in grads0.items():
+        arrays['gnorm/' + n] = np.float64(g.double().norm().item())
+        arrays['g/' + n] = sample_grad(g, True).numpy().copy()
+    rl = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for mode, dt, scale in AC_MODES:
+        model.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            with torch.autocast('cpu', dtype=dt):
+                o = model(v.detach(), t.detach(), vmask, tmask)
+            ((o.float() * gy).sum() * scale).backward()
+        arrays[mode + '/out_rel_l2'] = np.float64(rl(o.detach().float(), out0))
+        named = dict(model.named_parameters())
+        arrays[mode + '/gs'] = np.array([rl(sample_grad(named[n].grad.detach().float() / scale, True), sample_grad(grads0[n], True)) for n in grads0])
+        print(f'[gen_golden] {tag}: reference under autocast {mode[3:]}: output rel-L2 {float(arrays[mode + "/out_rel_l2"]):.2e}')
+    meta['grad_names'] = list(grads0)
+    arrays['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f'{tag}.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'[gen_golden] {tag}: |out|={float(out0.norm()):.4f} params={sum(p.numel() for p in model.parameters())} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='all')
@@ -515,6 +561,9 @@ def main():
         # the generative model: tiny with full logits, full-size (64 000-way head) with a logits sample
         run_generative_case('generative_tiny', GEN_TINY, 41, True)
         run_generative_case('generative_full', GEN_FULL, 42, False)
+    if args.only in ('all', 'fusion'):
+        for i, (tag, case) in enumerate(FUSION_CASES.items()):
+            run_fusion_case(tag, case, 51 + i)
 
 
 if __name__ == '__main__':

@@ -122,3 +122,45 @@ def fixture_inputs(meta):
         dec_in[1, cut:] = 1
         labels[1, cut - 1:] = -100
     return px, ids, mask, dec_in, dmask, labels
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# stand-alone CrossAttentionFusion (reference src/modeling/fusion/fusion_approaches.py:59-281)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+
+def cross_attention_block(sd, p, v, t, vmask, tmask, num_heads):
+    """fusion_approaches.py:243-281: text attends to vision, vision attends to the updated text; post-LN, GELU FFN."""
+    a = vo.mha(sd, p + 'v2t_attention', t, v, v, num_heads, (~vmask) if vmask is not None else None)
+    t = vo.layer_norm(sd, p + 'v2t_norm1', t + a)
+    t = vo.layer_norm(sd, p + 'v2t_norm2', t + vo.linear(sd, p + 'v2t_ffn.3', F.gelu(vo.linear(sd, p + 'v2t_ffn.0', t))))
+    a = vo.mha(sd, p + 't2v_attention', v, t, t, num_heads, (~tmask) if tmask is not None else None)
+    v = vo.layer_norm(sd, p + 't2v_norm1', v + a)
+    v = vo.layer_norm(sd, p + 't2v_norm2', v + vo.linear(sd, p + 't2v_ffn.3', F.gelu(vo.linear(sd, p + 't2v_ffn.0', v))))
+    return v, t
+
+
+def cross_attention_fusion(sd, v, t, vmask=None, tmask=None, *, num_heads, fusion_method='concat'):
+    """fusion_approaches.py:143-188."""
+    if 'vision_projection.weight' in sd:
+        v = vo.linear(sd, 'vision_projection', v)
+    if 'text_projection.weight' in sd:
+        t = vo.linear(sd, 'text_projection', t)
+    for i in range(_count(sd, 'cross_attention_layers.{}.v2t_norm1.weight')):
+        v, t = cross_attention_block(sd, f'cross_attention_layers.{i}.', v, t, vmask, tmask, num_heads)
+    vp, tp = v.mean(dim=1), t.mean(dim=1)
+    fused = torch.cat([vp, tp], dim=-1) if fusion_method == 'concat' else (vp + tp if fusion_method == 'add' else vp * tp)
+    h = F.gelu(vo.layer_norm(sd, 'fusion_layer.1', vo.linear(sd, 'fusion_layer.0', fused)))
+    return vo.layer_norm(sd, 'fusion_layer.5', vo.linear(sd, 'fusion_layer.4', h))
+
+
+def fusion_fixture_inputs(meta):
+    from . import det_weights as dw
+    c, seed = meta['case'], meta['seed']
+    v = dw.normal('fusion.vision', (c['B'], c['V'], c['vision_dim']), seed)
+    t = dw.normal('fusion.text', (c['B'], c['T'], c['text_dim']), seed)
+    vmask = torch.ones(c['B'], c['V'], dtype=torch.bool)
+    tmask = torch.ones(c['B'], c['T'], dtype=torch.bool)
+    tmask[1, (c['T'] * 5) // 8:] = False
+    vmask[0, -2:] = False
+    gy = dw.normal('fusion.gy', (c['B'], c['output_dim']), seed)
+    return v, t, vmask, tmask, gy

@@ -113,3 +113,43 @@ def test_generative_training_mode_and_generate_run():
     gen = model.generate(px, ids, mask, max_length=6)
     assert gen.shape[0] == px.shape[0] and 2 <= gen.shape[1] <= 6 and bool((gen[:, 0] == model.config.bos_token_id).all())
     assert torch.equal(gen, model.generate(px, ids, mask, max_length=6))
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('tag', ['fusion_xattn_tiny', 'fusion_xattn_full'])
+def test_standalone_cross_attention_fusion_matches_the_reference(tag, mode):
+    """``src.modeling.fusion.CrossAttentionFusion`` (fusion_approaches.py:59-281) on the HIP ops against the
+    reference-run fixture: output within ENV x the reference's own autocast deviation, gradients within ENV_GRAD x its aggregate."""
+    import vqa_model_builder_amd as vqa
+    from vqa_model_builder_amd.modeling.fusion import CrossAttentionFusion, create_fusion_model
+    arrays, meta = load_golden(tag)
+    c = meta['case']
+    ac, scale = MODES[mode]
+    vqa.set_compute_dtype(mode)
+    try:
+        kw = {k: c[k] for k in ('vision_dim', 'text_dim', 'output_dim', 'num_attention_heads', 'num_layers', 'intermediate_dim', 'fusion_method')}
+        model = create_fusion_model('cross_attention', **kw)
+        assert isinstance(model, CrossAttentionFusion) and list(model.state_dict().keys()) == meta['keys']
+        model.load_state_dict(dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed']))
+        model = model.to(DEV).eval()
+        v, t, vmask, tmask, gy = [x.to(DEV) for x in go.fusion_fixture_inputs(meta)]
+        v.requires_grad_(True); t.requires_grad_(True)
+        out = model(v, t, vmask, tmask)
+        ((out * gy).sum() * scale).backward()
+        torch.cuda.synchronize()
+        e_out = rel_l2(out.detach().float().cpu().numpy(), arrays['out'])
+        env = float(arrays[ac + '/out_rel_l2'])
+        e_dv, e_dt = rel_l2((v.grad / scale).cpu().numpy(), arrays['dv']), rel_l2((t.grad / scale).cpu().numpy(), arrays['dt'])
+        named = dict(model.named_parameters())
+        num = den = ref_num = 0.0
+        for n, ref_e in zip(meta['grad_names'], arrays[ac + '/gs']):
+            gn = float(arrays['gnorm/' + n])
+            e = rel_l2(sample_grad(named[n].grad.detach().float().cpu() / scale, True).numpy(), arrays['g/' + n])
+            num += (e * gn) ** 2; den += gn ** 2; ref_num += (float(ref_e) * gn) ** 2
+        agg, ref_agg = (num / den) ** 0.5, (ref_num / den) ** 0.5
+        print(f'FUSION tag={tag} mode={mode} out_rel_l2={e_out:.3e} (reference under autocast {env:.3e}) dv={e_dv:.3e} dt={e_dt:.3e} '
+              f'grad_aggregate={agg:.3e} (reference {ref_agg:.3e})')
+        assert e_out <= ENV * env, (e_out, env)
+        assert agg <= ENV_GRAD * ref_agg and max(e_dv, e_dt) <= 4 * ENV_GRAD * max(ref_agg, env), (agg, ref_agg, e_dv, e_dt)
+    finally:
+        vqa.set_compute_dtype('bf16')

@@ -125,6 +125,33 @@ def test_generative_oracle_matches_reference(tag):
     assert n > 50
 
 
+@pytest.mark.parametrize('tag', ['fusion_xattn_tiny', 'fusion_xattn_full'])
+def test_standalone_cross_attention_fusion_oracle_matches_reference(tag):
+    """oracle/gen_oracle.py: cross_attention_fusion (bidirectional blocks with both padding masks, mean pooling over all tokens,
+    Linear -> LayerNorm -> GELU -> Linear -> LayerNorm) against the reference's own module: output, input and parameter gradients."""
+    import torch
+    from oracle import det_weights as dw
+    from oracle import gen_oracle as go
+    from oracle.gen_golden import sample_grad
+    arrays, meta = load_golden(tag)
+    c = meta['case']
+    sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
+    assert dw.checksum(sd) == meta['weights_checksum']
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    v, t, vmask, tmask, gy = go.fusion_fixture_inputs(meta)
+    v.requires_grad_(True); t.requires_grad_(True)
+    out = go.cross_attention_fusion(leaves, v, t, vmask, tmask, num_heads=c['num_attention_heads'], fusion_method=c['fusion_method'])
+    (out * gy).sum().backward()
+    rl = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()) / (np.linalg.norm(np.asarray(b, np.float64)) + 1e-30))
+    assert rl(out.detach().numpy(), arrays['out']) < 1e-5
+    assert rl(v.grad.numpy(), arrays['dv']) < 1e-4 and rl(t.grad.numpy(), arrays['dt']) < 1e-4
+    gmax = max(float(arrays['gnorm/' + n]) for n in meta['grad_names'])
+    for n in meta['grad_names']:
+        if float(arrays['gnorm/' + n]) < 1e-6 * gmax:
+            continue
+        assert rl(sample_grad(leaves[n].grad, True).numpy(), arrays['g/' + n]) < (2e-3 if float(arrays['gnorm/' + n]) < 1e-4 * gmax else 2e-4), n
+
+
 def test_fixtures_carry_the_reference_autocast_envelopes():
     """Every model fixture stores what the reference itself does under torch.autocast (bf16 and fp16): the GPU parity gates
     are multiples of THESE numbers.  Sanity: fp16 is the tighter one, and both are finite and in a plausible band."""

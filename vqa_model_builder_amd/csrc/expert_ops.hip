@@ -127,6 +127,22 @@ __global__ void scatter_stride_kernel(const float* __restrict__ src, float* __re
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) dst[i * stride_el + offset] = src[i];
 }
 
+// y = dropout(act(x)) for an activation that does not ride in a GEMM epilogue (Linear -> LayerNorm -> GELU -> Dropout of the
+// stand-alone fusion modules); also writes the 16-bit copy of x the backward (vqa_act_drop_bwd) reads
+__global__ void act_drop_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, h16_t* __restrict__ yb, h16_t* __restrict__ pre, size_t n, int act,
+                                    float p, float inv_keep, uint64_t seed, uint32_t stream) {
+    if (p > 0.f) seed = resolve_seed(seed);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v0 = x[i];
+        if (pre) pre[i] = (h16_t)v0;
+        float v = act_fwd(v0, act);
+        if (p > 0.f) v *= dropout_scale(seed, stream, i, p, inv_keep);
+        if (y) y[i] = v;
+        if (yb) yb[i] = (h16_t)v;
+    }
+}
+
 constexpr int MAX_E = 16;
 struct PtrsC { const float* p[MAX_E]; };
 struct PtrsM { float* p[MAX_E]; };
@@ -228,6 +244,14 @@ int vqa_scatter_stride_f32(const float* src, float* dst, size_t n, int stride, i
     if (!src || !dst || stride <= 0 || offset < 0 || offset >= stride) return VQA_ERR_ARG;
     if (n == 0) return VQA_OK;
     hipLaunchKernelGGL(scatter_stride_kernel, dim3(grid_of(n, 256, 4096)), dim3(256), 0, (hipStream_t)s, src, dst, n, stride, offset);
+    return (int)hipGetLastError();
+}
+
+int vqa_act_drop_fwd(const float* x, float* y, void* y_bf16, void* pre_bf16, size_t n, int act, float p, uint64_t seed, uint32_t stream, vqa_stream_t s) {
+    if (!x || (!y && !y_bf16) || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(act_drop_fwd_kernel, dim3(grid_of(n, 256, 2048)), dim3(256), 0, (hipStream_t)s, x, y, (h16_t*)y_bf16, (h16_t*)pre_bf16, n, act, p,
+                       p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
     return (int)hipGetLastError();
 }
 

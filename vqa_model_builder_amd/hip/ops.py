@@ -233,7 +233,38 @@ def dropout(x, p, training):
     return _DropoutFn.apply(x, Drop(p, new_seed(), 91))
 
 
-# ---- activations as stand-alone ops are never needed: they ride in linear(act=...) -------------------------------------
+# ---- stand-alone activation (+ dropout): only where an activation does NOT follow a Linear directly (Linear -> LayerNorm -> GELU) ------
+
+class _ActDropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, drop):
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        pre = torch.empty(x.shape, dtype=K.HALF(), device=x.device)
+        K._chk(K.L().vqa_act_drop_fwd(x.data_ptr(), y.data_ptr(), None, pre.data_ptr(), x.numel(), act, drop.p, drop.seed, drop.stream, K._stream()),
+               'vqa_act_drop_fwd')
+        ctx.save_for_backward(pre)
+        ctx.meta = (act, drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pre,) = ctx.saved_tensors
+        act, drop = ctx.meta
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(dy)
+        K._chk(K.L().vqa_act_drop_bwd(dy.data_ptr(), pre.data_ptr(), act, dx.data_ptr(), None, dy.numel(), drop.p, drop.seed, drop.stream, K._stream()),
+               'vqa_act_drop_bwd')
+        return dx, None, None
+
+
+def activation(x, act, dropout_p=0.0, training=False):
+    """dropout(act(x)) as one launch each way."""
+    _need_cuda(x, 'activation')
+    drop = Drop(dropout_p, new_seed(), 93) if (training and dropout_p > 0) else NO_DROP
+    return _ActDropFn.apply(x, act, drop)
+
+
 
 # ---- cross entropy + argmax ------------------------------------------------------------------------------------------------
 
