@@ -392,7 +392,7 @@ def main():
             seg = run_workload(args.workload, args, device, world, rank, dist, want_roofline=False)
             args.force_segmented = False
             BUS = 300e9                           # assumed all-reduce bus bandwidth of an 8-GPU xGMI node (7 links x ~153 GB/s per GPU, ~30 % of it)
-            sb, sm = seg.get('segment_bytes', {}), seg.get('segment_ms', {})
+            sb, sm, sg = seg.get('segment_bytes', {}), seg.get('segment_ms', {}), seg.get('segment_gather_bytes_per_rank', {})
             total = seg['ms_per_step']
             t_opt = max(0.0, total - sum(sm.values()))
             blocks = [k for k in sm if k != 'F']                 # in replay order: H, T, V (, V2)
@@ -402,7 +402,8 @@ def main():
                 ready, end = sm.get('F', 0.0), 0.0
                 for k in blocks:
                     ready += sm.get(k, 0.0)
-                    end = max(ready, end) + 2 * (7 / 8) * sb.get(k, 0) * wire / BUS * 1e3
+                    dense = sb.get(k, 0) - sg.get(k, 0)              # measured at world 1: the gather part counted once
+                    end = max(ready, end) + (2 * (7 / 8) * dense * wire + 7 * sg.get(k, 0)) / BUS * 1e3      # ring all-reduce + all-gather of 8 ranks' rows
                 exposed = max(0.0, end - ready)
                 step = ready + exposed + t_opt
                 return {'exposed_allreduce_ms': round(exposed, 3), 'ms_per_step': round(step, 3), 'scaling_vs_1gpu': round(8 * main_res['ms_per_step'] / step, 2)}
@@ -431,7 +432,7 @@ def main():
                        'global_batch': args.batch * world, 'image': '3x224x224', 'seq_len': 64,
                        'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
                        'launch': main_res['launch'], 'final_loss': main_res['final_loss'],
-                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'grad_dtype', 'exposed_comm_ms', 'segment_bytes', 'segment_ms') if k in main_res}},
+                       **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'grad_dtype', 'exposed_comm_ms', 'segment_bytes', 'segment_ms', 'segment_gather_bytes_per_rank') if k in main_res}},
             'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res, 'dp_model': dp_model,
         }
         print(json.dumps(line), flush=True)

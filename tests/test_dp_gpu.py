@@ -104,7 +104,8 @@ def _train_worker(rank, world, port, q, mode):
                                   segmented=False if 'flat' in mode else None)
             losses = [float('nan')] * warm + [gs(batch).item() for _ in range(n - warm)]
             torch.cuda.synchronize()
-            info = dict(segmented=gs.segmented, stats=gs.comm_stats(), describe=gs.describe())
+            info = dict(segmented=gs.segmented, stats=gs.comm_stats(), describe=gs.describe(),
+                        sparse=sum(len(sg.get('sparse', [])) for sg in getattr(red, '_segments', {}).values()))
         torch.cuda.synchronize()
         sig = float(sum(p.detach().double().abs().sum().item() for p in params))
         q.put((rank, losses, sig, info))
@@ -140,6 +141,7 @@ def test_graphed_data_parallel_step_matches_eager_data_parallel_step(mode, tol):
         st = graph[0][2]['stats']
         assert set(st['segment_bytes']) == {'H', 'T', 'T2', 'V', 'V2'} and st['exposed_comm_ms'] >= 0.0, st      # each encoder backward in two graphs
         assert set(st['segment_ms']) == {'F', 'H', 'T', 'T2', 'V', 'V2'}, st
+        assert graph[0][2]['sparse'] == 1                  # the word-embedding gradient travelled as gathered (ids, rows)
         assert min(st['segment_bytes'].values()) > 0, st
     for r in (0, 1):
         le, lg = eager[r][0], graph[r][0]

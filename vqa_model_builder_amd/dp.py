@@ -239,20 +239,32 @@ class GradReducer:
 
     # ---- captured step: per-segment in-place exchange ------------------------------------------------------------------
     @torch.no_grad()
-    def prepare_static(self, segment_of: Optional[Dict[int, str]] = None, order: Sequence[str] = ('all',)):
+    def prepare_static(self, segment_of: Optional[Dict[int, str]] = None, order: Sequence[str] = ('all',), sparse=()):
         """HIP-graph mode (graph.GraphedTrainStep), called once after the backward graphs were captured: from then on every
         replay writes the gradients to the SAME addresses.  The block runners' gradient arenas (one storage per encoder / fusion
         layer, holding every gradient of the block) are all-reduced IN PLACE, whole -- no packing pass, no second copy of 0.9 GB
         of gradients; the few parameters with a storage of their own are packed into one small buffer per segment and ``p.grad``
         re-pointed at it.  ``segment_of`` maps id(parameter) -> segment name (the backward graph that produces its gradient),
         ``order`` lists the segments in the order their graphs replay: ``reduce_segment(name)`` exchanges one of them.  The set
-        of present gradients is the capture's (a captured step has no data-dependent control flow)."""
+        of present gradients is the capture's (a captured step has no data-dependent control flow).
+        ``sparse``: callables returning ``(parameter, ids [M], rows [M, D] fp32, pad_id)`` for embedding tables whose gradient is a
+        scatter of M rows (the 64 001 x 768 word table: 196 MB dense, 6 MB of rows at batch 32): the table is left out of the
+        all-reduce; every rank all-gathers (ids, rows) and adds the other ranks' rows to its own table gradient.  The sum is the one the
+        dense all-reduce gives, in a different (fp32) summation order."""
         self._segments = {}
+        sparse_of = {}
+        for getter in sparse:
+            got = getter()
+            if got is not None and got[0].grad is not None:
+                sparse_of[id(got[0])] = getter
         for name in order:
-            by_storage = {}
+            by_storage, sparse_here = {}, []
             for b in self.buckets:
                 for p in b.params:
                     if p.grad is None or (segment_of is not None and segment_of.get(id(p), order[0]) != name):
+                        continue
+                    if id(p) in sparse_of:
+                        sparse_here.append((p, sparse_of[id(p)]))
                         continue
                     us = p.grad.untyped_storage()
                     by_storage.setdefault(us.data_ptr(), [us, []])[1].append(p)
@@ -290,8 +302,13 @@ class GradReducer:
             stage = None
             if self.grad_dtype == 'bf16':
                 stage = [torch.empty(f.numel(), dtype=torch.bfloat16, device=f.device) for f in inplace]
-            self._segments[name] = {'flats': inplace, 'pack': pack, 'stage': stage, 'works': [],
-                                    'bytes': sum(f.numel() for f in inplace) * (2 if stage is not None else 4)}
+            nbytes = sum(f.numel() for f in inplace) * (2 if stage is not None else 4)
+            gather = 0
+            for p, getter in sparse_here:
+                _, ids, rows, _ = getter()
+                gather += rows.numel() * 4 + ids.numel() * 4          # per rank; every rank receives world x this
+            nbytes += self.world * gather
+            self._segments[name] = {'flats': inplace, 'pack': pack, 'stage': stage, 'works': [], 'bytes': nbytes, 'sparse': sparse_here, 'gathered': [], 'gather_bytes_per_rank': gather}
         self._inplace = [f for s in self._segments.values() for f in s['flats']]
         return self
 
@@ -315,6 +332,16 @@ class GradReducer:
         seg = self._segments[name]
         bufs = seg['stage'] if seg['stage'] is not None else seg['flats']
         seg['works'] = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in bufs]
+        seg['gathered'] = []
+        for p, getter in seg['sparse']:
+            _, ids, rows, pad = getter()
+            ids32 = torch.where(ids == pad, torch.full_like(ids, -1), ids).to(torch.int32)       # padding_idx rows carry no gradient
+            rows = rows.contiguous()
+            ids_all = [torch.empty_like(ids32) for _ in range(self.world)]
+            rows_all = [torch.empty_like(rows) for _ in range(self.world)]
+            seg['works'].append(dist.all_gather(ids_all, ids32, group=self.group, async_op=True))
+            seg['works'].append(dist.all_gather(rows_all, rows, group=self.group, async_op=True))
+            seg['gathered'].append((p, ids_all, rows_all))
 
     @torch.no_grad()
     def wait_segment(self, name: str):
@@ -325,6 +352,18 @@ class GradReducer:
         if seg['stage'] is not None:
             for f, s in zip(seg['flats'], seg['stage']):
                 f.copy_(s)                                   # bf16 sum -> the fp32 arena the optimiser reads
+        if seg['gathered']:
+            from .hip import kernels as K
+            rank = dist.get_rank(self.group)
+            for p, ids_all, rows_all in seg['gathered']:
+                V, D = p.grad.shape
+                for r in range(self.world):
+                    if r != rank:                            # this rank's own rows are in its table gradient already
+                        K._chk(K.L().vqa_embedding_rows_bwd(rows_all[r].data_ptr(), ids_all[r].data_ptr(), p.grad.data_ptr(), ids_all[r].numel(), D, V,
+                                                            K._stream()), 'vqa_embedding_rows_bwd')
+                if self.average and self.world > 1:
+                    p.grad.mul_(1.0 / self.world)
+            seg['gathered'] = []
         if self.average and self.world > 1:
             for f in seg['flats']:
                 f.mul_(1.0 / self.world)
@@ -339,6 +378,10 @@ class GradReducer:
             self.reduce_segment(name)
         for name in self._segments:
             self.wait_segment(name)
+
+    def segment_gather_bytes(self) -> Dict[str, int]:
+        """Bytes each rank contributes to a segment's all-gathers (sparse embedding rows); included world-fold in segment_bytes()."""
+        return {k: s.get('gather_bytes_per_rank', 0) for k, s in getattr(self, '_segments', {}).items()}
 
     def segment_bytes(self) -> Dict[str, int]:
         return {k: v['bytes'] for k, v in (self._segments or {}).items()}

@@ -46,7 +46,7 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
-                 moe_branches: int = 1, split_encoders: bool = True):
+                 moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -55,6 +55,7 @@ class GraphedTrainStep:
         ``loss_of(output)`` picks the scalar to differentiate (default ``output.loss``).  ``reducer``: a ``dp.GradReducer``
         without hooks attached.  ``parallel_towers``: the vision encoder runs as a parallel branch (measured on MI355X, cfg2,
         B=32: 13.7 -> 10.6 ms/step).  ``defer_wgrad``: weight-gradient GEMMs are issued grouped at the end of their graph.
+        ``sparse_embeddings`` (segmented step): the word-embedding gradient is exchanged as gathered (ids, rows) (dp.prepare_static).
         ``split_encoders`` (segmented step): each encoder's backward as two graphs (upper / lower half of its layers).
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
@@ -142,7 +143,11 @@ class GraphedTrainStep:
             seg_of = {}
             for n, p in model.named_parameters():
                 seg_of[id(p)] = self._segment_of(n)
-            reducer.prepare_static(seg_of, order)
+            sparse = []
+            enc = getattr(getattr(model, 'text_encoder', None), 'encoder', None)
+            if sparse_embeddings and hasattr(enc, 'sparse_grad_rows'):
+                sparse.append(enc.sparse_grad_rows)           # the word table travels as (ids, rows), not as a 196-MB dense gradient
+            reducer.prepare_static(seg_of, order, sparse=sparse)
             # the device-side packing of each segment (stand-alone gradients -> pack buffer, bf16 wire copies) is a small graph of
             # its own, replayed right behind the segment's backward graph
             for name in order:
@@ -261,7 +266,8 @@ class GraphedTrainStep:
             return {}
         self._exposed_ms = [e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in self._exposed_ms]
         v = sorted(self._exposed_ms)
-        out = {'exposed_comm_ms': round(v[len(v) // 2], 3), 'segment_bytes': self.reducer.segment_bytes()}
+        out = {'exposed_comm_ms': round(v[len(v) // 2], 3), 'segment_bytes': self.reducer.segment_bytes(),
+               'segment_gather_bytes_per_rank': self.reducer.segment_gather_bytes()}
         if self._segment_marks:
             # median GPU time of each graph of the step (F: encoders forward, H: fusion + head forward / backward, T / V: encoder backward)
             seg = {}

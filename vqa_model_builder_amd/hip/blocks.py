@@ -218,6 +218,8 @@ class ClipRunner:
 # ==================================================================================================================
 
 class RobertaRunner:
+    last_embed_rows = None
+
     def __init__(self, W, num_layers, D, heads, inter, pad_id=1, hidden_drop=0.1, attn_drop=0.1, eps=1e-5):
         self.W, self.L, self.D, self.H, self.I = W, num_layers, D, heads, inter
         self.pad, self.pd, self.pa, self.eps = pad_id, hidden_drop, attn_drop, eps
@@ -293,6 +295,7 @@ class RobertaRunner:
         du, _, _, _ = K.layernorm_bwd(dx, saved['u'], saved['mean0'], saved['rstd0'], W.p('emb_ln.w'), M, D,
                                       drop=Drop(pd, seed, 1), drop_mode=2, dgamma=G['emb_ln.w'], dbeta=G['emb_ln.b'], defer=True)
         K.roberta_embed_bwd(du, saved['ids'], saved['pos_ids'], G['word'], G['pos'], G['type'], B, S, D, self.pad)
+        self.last_embed_rows = (saved['ids'], du)          # what was scattered into the word table: the data-parallel exchange sends THIS
         K.ln_reduce_flush()
         K.wgrad_join()
         return G

@@ -319,6 +319,16 @@ class RobertaBackbone(_ResumableBackward, nn.Module):
         self._W.shadows.refresh(ids.device)
         return self._runner.forward(ids, mask, self.training)
 
+    def sparse_grad_rows(self):
+        """(word-embedding parameter, token ids int64 [M], gradient rows fp32 [M, D], pad id) of the LAST backward, or None: the
+        word table's gradient is M <= batch x seq rows scattered into a [64 001, 768] table -- the data-parallel exchange gathers
+        the rows instead of all-reducing 196 MB of mostly zeros (dp.GradReducer.prepare_static)."""
+        rows = self._runner.last_embed_rows
+        w = self.embeddings.word_embeddings.weight
+        if rows is None or not w.requires_grad:
+            return None
+        return w, rows[0].reshape(-1), rows[1], self.config.pad_token_id
+
     def _hip_backward(self, saved, dout, needs):
         return [None, None], _split_grads(self._flat, self._run_backward(saved, dout))
 
