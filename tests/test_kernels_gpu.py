@@ -231,7 +231,10 @@ def _ref_attn(q, k, v, B, H, Sq, Skv, Dh, mask):
 @pytest.mark.parametrize('B,H,Sq,Skv,Dh,masked', [(3, 4, 8, 8, 16, True), (2, 12, 50, 50, 64, False), (2, 12, 64, 64, 64, True),
                                                   (2, 8, 64, 50, 96, False), (3, 8, 4, 1, 256, False), (2, 8, 4, 4, 256, False),
                                                   (2, 4, 17, 10, 16, True), (1, 2, 100, 128, 32, True),
-                                                  (2, 8, 100, 100, 256, False), (2, 8, 100, 1, 256, False), (2, 8, 1, 100, 256, True)])
+                                                  (2, 8, 100, 100, 256, False), (2, 8, 100, 1, 256, False), (2, 8, 1, 100, 256, True),
+                                                  # 65 - 128 keys on the MFMA kernels (8 key tiles): the generative model's 114-token memory
+                                                  (2, 8, 64, 114, 96, True), (2, 8, 33, 114, 96, False), (2, 8, 114, 114, 96, True), (3, 4, 17, 100, 32, False),
+                                                  (2, 2, 64, 128, 128, True), (2, 12, 50, 65, 64, False)])
 def test_attention_fwd_bwd(B, H, Sq, Skv, Dh, masked):
     D = H * Dh
     # packed layouts with non-trivial leading dims: q in [.., 3D] at col 0, k/v in a [.., 2D] buffer
@@ -722,7 +725,7 @@ def test_layernorm_backward_deferred_grouped_reduce_and_accumulate_mode():
 def test_attention_backward_fused_bias_gradient_sums():
     """dq/dk/dv column sums accumulated by the attention backward (MFMA kernel: per-workgroup LDS reduction + one atomic per
     column; generic kernel: separate passes) == column sums of the bf16 gradients it wrote."""
-    for (B, H, Sq, Skv, Dh) in [(4, 12, 50, 50, 64), (3, 8, 64, 40, 96), (2, 4, 100, 100, 32)]:
+    for (B, H, Sq, Skv, Dh) in [(4, 12, 50, 50, 64), (3, 8, 64, 40, 96), (2, 4, 100, 100, 32), (2, 8, 40, 114, 96), (2, 4, 64, 128, 64)]:
         D = H * Dh
         q, k, v = [rnd((B * s, D), i).to(DEV).to(BF) for i, s in ((1, Sq), (2, Skv), (3, Skv))]
         do = rnd((B * Sq, D), 4).to(DEV).to(BF)

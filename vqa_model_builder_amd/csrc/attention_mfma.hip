@@ -1,5 +1,7 @@
 // MFMA attention core for the hot shapes of the path (Sq, Skv <= 64; head dim 32/64/96/128): CLIP ViT (50x50, Dh 64),
-// PhoBERT (64x64, Dh 64, key-padding mask) and the fusion block (64x64 self, 64x50 cross, Dh 96).
+// PhoBERT (64x64, Dh 64, key-padding mask) and the fusion block (64x64 self, 64x50 cross, Dh 96) -- and, with KT = 8 key tiles,
+// up to 128 keys (the generative model's 114-token fused memory): forward for any Sq <= 128 (64-row query blocks on gridDim.y),
+// backward for Sq <= 64 (its dK / dV sums run over ONE query block).
 //
 // One workgroup (4 wavefronts) per (batch, head); Q, K, V (and dO in backward) of the head are staged once in LDS
 // (row pitch Dh*2+16 B: conflict-free ds_read_b128 row fragments, 8-B aligned transposing reads).  Wave w owns query
@@ -17,62 +19,62 @@
 
 namespace {
 
-template <int DH>
+template <int DH, int KT>
 __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MArgs a_in) {
     MArgs a = a_in;
     if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
-    constexpr int PITCH = DH * 2 + 16;
-    __shared__ __attribute__((aligned(16))) char smem[3 * 64 * PITCH];
-    char *Qs = smem, *Ks = smem + 64 * PITCH, *Vs = smem + 2 * 64 * PITCH;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4;
-    stage_tile<DH>(Qs, a.q + (size_t)b * a.Sq * a.ldq + h * DH, a.Sq, a.ldq, tid);
-    stage_tile<DH>(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * DH, a.Skv, a.ldk, tid);
-    stage_tile<DH>(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * DH, a.Skv, a.ldv, tid);
+    constexpr int PITCH = DH * 2 + 16, KR = 16 * KT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];             // Q block [64] | K [KR] | V [KR]
+    char *Qs = smem, *Ks = smem + 64 * PITCH, *Vs = Ks + KR * PITCH;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, q0 = 64 * blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    stage_tile<DH>(Qs, a.q + ((size_t)b * a.Sq + q0) * a.ldq + h * DH, a.Sq - q0, a.ldq, tid);
+    stage_tile<DH, KR>(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * DH, a.Skv, a.ldk, tid);
+    stage_tile<DH, KR>(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * DH, a.Skv, a.ldv, tid);
     __syncthreads();
-    if (16 * w >= a.Sq) return;                      // whole wave beyond the last query row (no barrier follows)
-    attn_core_fwd<DH>(a, Qs, Ks, Vs, b, h, w, lane);
+    if (q0 + 16 * w >= a.Sq) return;                 // whole wave beyond the last query row (no barrier follows)
+    attn_core_fwd<DH, KT>(a, Qs, Ks, Vs, b, h, w, lane, q0);
 }
 
-template <int DH>
+template <int DH, int KT>
 __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
     MArgs a = a_in;
     if (a.drop_p > 0.f) a.seed = resolve_seed(a.seed);
-    constexpr int PITCH = DH * 2 + 16;
+    constexpr int PITCH = DH * 2 + 16, KR = 16 * KT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Qs = smem, *Ks = Qs + 64 * PITCH, *Vs = Ks + 64 * PITCH, *Gs = Vs + 64 * PITCH;
-    char *Pt = Gs + 64 * PITCH, *Dt = Pt + 64 * PT;                  // [kv][q] bf16 tiles
+    char *Qs = smem, *Ks = Qs + 64 * PITCH, *Vs = Ks + KR * PITCH, *Gs = Vs + KR * PITCH;
+    char *Pt = Gs + 64 * PITCH, *Dt = Pt + KR * PT;                  // [kv][q] bf16 tiles
     __shared__ __attribute__((aligned(16))) float cs_part[3][4][DH];  // bias-gradient partials: {dq, dk, dv} x wave x column
     const bool want_cs = a.dq_cs || a.dk_cs || a.dv_cs;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
     stage_tile<DH>(Qs, a.q + (size_t)b * a.Sq * a.ldq + h * DH, a.Sq, a.ldq, tid);
-    stage_tile<DH>(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * DH, a.Skv, a.ldk, tid);
-    stage_tile<DH>(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * DH, a.Skv, a.ldv, tid);
+    stage_tile<DH, KR>(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * DH, a.Skv, a.ldk, tid);
+    stage_tile<DH, KR>(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * DH, a.Skv, a.ldv, tid);
     stage_tile<DH>(Gs, a.d_o + (size_t)b * a.Sq * a.ldd_o + h * DH, a.Sq, a.ldd_o, tid);
     __syncthreads();
     // ---- phase 1: this wave's 16 query rows
     {
-        f32x4 pn[4], ks[4], dp[4];
-        scores_softmax<DH>(a, Qs, Ks, b, h, w, lane, pn, ks);
+        f32x4 pn[KT], ks[KT], dp[KT];
+        scores_softmax<DH, KT>(a, Qs, Ks, b, h, w, lane, pn, ks);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < KT; ++t) dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < DH / 32; ++kk) {
             const h16x8 gf = row_frag(Gs, PITCH, 16 * w, 32 * kk, lane);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dp[t] = VQA_MFMA16(row_frag(Vs, PITCH, 16 * t, 32 * kk, lane), gf, dp[t]);
+            for (int t = 0; t < KT; ++t) dp[t] = VQA_MFMA16(row_frag(Vs, PITCH, 16 * t, 32 * kk, lane), gf, dp[t]);
         }
         float delta = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < KT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { dp[t][r] *= ks[t][r]; delta += pn[t][r] * dp[t][r]; }
         delta = xor32_sum(xor16_sum(delta));
         const int q = 16 * w + i;
         const bool qok = q < a.Sq;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < KT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ds = qok ? pn[t][r] * (dp[t][r] - delta) * a.scale : 0.f;
@@ -83,14 +85,14 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
                 *reinterpret_cast<h16_t*>(Dt + kv * PT + q * 2) = (h16_t)ds;
             }
         // dQ^T = K^T dS^T, dS^T straight from the accumulator registers
-        h16x8 df[2];
+        h16x8 df[KT / 2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) df[u] = pack8(dp[2 * u], dp[2 * u + 1]);
+        for (int u = 0; u < KT / 2; ++u) df[u] = pack8(dp[2 * u], dp[2 * u + 1]);
 #pragma unroll 1
         for (int dt = 0; dt < DH / 16; ++dt) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < KT / 2; ++u)
                 o = VQA_MFMA16(col_frag(Ks, PITCH, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, lane), df[u], o);
             h16x4 ob;
 #pragma unroll
@@ -100,18 +102,19 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
         }
     }
     __syncthreads();
-    // ---- phase 2: this wave's 16 key rows:  dV^T = dO^T P',  dK^T = Q^T dS   (k = q, natural order)
-    const int kv = 16 * w + i;
-    const bool kok = kv < a.Skv;
+    // ---- phase 2: this wave's 16 key rows of every 64-key pass:  dV^T = dO^T P',  dK^T = Q^T dS   (k = q, natural order)
     // a real loop: these kernels run once per workgroup from a cold instruction cache -- measured, their run time WAS their code
-    // size (fwd 1870 instructions / 8.3 us, bwd 2800 / 14 us at ~80 cycles per 64-B line); each dt iteration is independent
+    // size (fwd 1870 instructions / 8.3 us, bwd 2800 / 14 us at ~80 cycles per 64-B line); each (pass, dt) iteration is independent
 #pragma unroll 1
-    for (int dt = 0; dt < DH / 16; ++dt) {
+    for (int it = 0; it < (KT / 4) * (DH / 16); ++it) {
+        const int kp = it / (DH / 16), dt = it % (DH / 16);
+        const int kv = 64 * kp + 16 * w + i;
+        const bool kok = kv < a.Skv;
         f32x4 ov = {0.f, 0.f, 0.f, 0.f}, ok = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const h16x8 pf = row_frag(Pt, PT, 16 * w, 32 * u, lane);
-            const h16x8 sf = row_frag(Dt, PT, 16 * w, 32 * u, lane);
+            const h16x8 pf = row_frag(Pt, PT, 64 * kp + 16 * w, 32 * u, lane);
+            const h16x8 sf = row_frag(Dt, PT, 64 * kp + 16 * w, 32 * u, lane);
             ov = VQA_MFMA16(col_frag(Gs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), pf, ov);
             ok = VQA_MFMA16(col_frag(Qs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), sf, ok);
         }
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
             *reinterpret_cast<h16x4*>(a.dk + ((size_t)b * a.Skv + kv) * a.lddk + h * DH + 16 * dt + 4 * g) = bk;
         }
         if (want_cs) {
-            slab_colsum(&cs_part[1][w][16 * dt + 4 * g], bk, kok, lane);
-            slab_colsum(&cs_part[2][w][16 * dt + 4 * g], bv, kok, lane);
+            slab_colsum(&cs_part[1][w][16 * dt + 4 * g], bk, kok, lane, kp > 0);
+            slab_colsum(&cs_part[2][w][16 * dt + 4 * g], bv, kok, lane, kp > 0);
         }
     }
     if (want_cs) {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
 }
 
 bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
-    if (d->Sq > 64 || d->Skv > 64 || d->Sq < 1 || d->Skv < 1) return false;
+    if (d->Sq < 1 || d->Skv < 1 || d->Skv > 128 || d->Sq > (bwd ? 64 : 128)) return false;       // backward: one 64-row query block
     if (d->Dh != 32 && d->Dh != 64 && d->Dh != 96 && d->Dh != 128) return false;
     if ((d->ldq | d->ldk | d->ldv | d->ldo) % 8) return false;
     if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return false;
@@ -161,39 +164,52 @@ bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
 }  // namespace
 
 // returns -1 when the shape is not covered (caller falls back to the generic kernel), else a hipError_t / 0
-int vqa_attention_mfma_fwd(const VqaAttnDesc* d, hipStream_t s) {
-    MArgs a;
-    if (!fill(d, a, false)) return -1;
-    dim3 grid(a.B * a.H), block(256);
-    switch (d->Dh) {
-        case 32: hipLaunchKernelGGL(attn_mfma_fwd_kernel<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(attn_mfma_fwd_kernel<64>, grid, block, 0, s, a); break;
-        case 96: hipLaunchKernelGGL(attn_mfma_fwd_kernel<96>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(attn_mfma_fwd_kernel<128>, grid, block, 0, s, a); break;
-    }
-    return (int)hipGetLastError();
-}
-
-template <int DH>
-static int launch_bwd(const MArgs& a, hipStream_t s) {
-    constexpr size_t LDS = 4 * 64 * (DH * 2 + 16) + 2 * 64 * PT;
+template <int DH, int KT>
+static int launch_fwd(const MArgs& a, hipStream_t s) {
+    constexpr size_t LDS = (64 + 2 * 16 * KT) * (DH * 2 + 16);
     static bool attr = false;
     if (LDS > 64 * 1024 && !attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel<DH, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(attn_mfma_bwd_kernel<DH>, dim3(a.B * a.H), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<DH, KT>), dim3(a.B * a.H, (a.Sq + 63) / 64), dim3(256), LDS, s, a);
+    return (int)hipGetLastError();
+}
+
+int vqa_attention_mfma_fwd(const VqaAttnDesc* d, hipStream_t s) {
+    MArgs a;
+    if (!fill(d, a, false)) return -1;
+    const bool wide = a.Skv > 64;
+    switch (d->Dh) {
+        case 32: return wide ? launch_fwd<32, 8>(a, s) : launch_fwd<32, 4>(a, s);
+        case 64: return wide ? launch_fwd<64, 8>(a, s) : launch_fwd<64, 4>(a, s);
+        case 96: return wide ? launch_fwd<96, 8>(a, s) : launch_fwd<96, 4>(a, s);
+        default: return wide ? launch_fwd<128, 8>(a, s) : launch_fwd<128, 4>(a, s);
+    }
+}
+
+template <int DH, int KT>
+static int launch_bwd(const MArgs& a, hipStream_t s) {
+    constexpr size_t LDS = (2 * 64 + 2 * 16 * KT) * (DH * 2 + 16) + 2 * 16 * KT * PT;
+    static bool attr = false;
+    if (LDS > 64 * 1024 && !attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel<DH, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_mfma_bwd_kernel<DH, KT>), dim3(a.B * a.H), dim3(256), LDS, s, a);
     return (int)hipGetLastError();
 }
 
 int vqa_attention_mfma_bwd(const VqaAttnDesc* d, hipStream_t s) {
     MArgs a;
     if (!fill(d, a, true)) return -1;
+    const bool wide = a.Skv > 64;
     switch (d->Dh) {
-        case 32: return launch_bwd<32>(a, s);
-        case 64: return launch_bwd<64>(a, s);
-        case 96: return launch_bwd<96>(a, s);
-        default: return launch_bwd<128>(a, s);
+        case 32: return wide ? launch_bwd<32, 8>(a, s) : launch_bwd<32, 4>(a, s);
+        case 64: return wide ? launch_bwd<64, 8>(a, s) : launch_bwd<64, 4>(a, s);
+        case 96: return wide ? launch_bwd<96, 8>(a, s) : launch_bwd<96, 4>(a, s);
+        default: return wide ? launch_bwd<128, 8>(a, s) : launch_bwd<128, 4>(a, s);
     }
 }

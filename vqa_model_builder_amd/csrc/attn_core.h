@@ -22,22 +22,25 @@ struct MArgs {
 // fold the 16 row-lanes; lanes i == 0 leave their 4 columns in the wave's LDS row.  The workgroup's four rows are summed
 // at the end and added to the accumulator ONCE per workgroup: B adders per address (one per batch element), inside the
 // range where float atomics keep their rate (per-wave adds -- 4 B adders -- ran the kernel 2.4x slower).
-__device__ __forceinline__ void slab_colsum(float* lds_row, const h16x4& v, bool row_ok, int lane) {
+__device__ __forceinline__ void slab_colsum(float* lds_row, const h16x4& v, bool row_ok, int lane, bool accumulate = false) {
     f32x4 c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) c[r] = row_ok ? (float)v[r] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) c[r] = row_sum16(c[r]);            // DPP rotates inside the 16-lane row: no LDS round trips
-    if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(lds_row) = c;
+    if ((lane & 15) == 0) {
+        if (accumulate) c += *reinterpret_cast<f32x4*>(lds_row);   // second 64-key pass of the same wave (its own LDS row)
+        *reinterpret_cast<f32x4*>(lds_row) = c;
+    }
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr int PT = 144;          // pitch of the [kv][q] P^T / dS^T tiles (64 bf16 + 16 B)
 
-template <int DH>
+template <int DH, int ROWS = 64>
 __device__ __forceinline__ void stage_tile(char* lds, const h16_t* g, int rows, int ld, int tid) {
     constexpr int PITCH = DH * 2 + 16, CPR = DH / 8;          // 16-B chunks per row
-    for (int c = tid; c < 64 * CPR; c += 256) {
+    for (int c = tid; c < ROWS * CPR; c += 256) {
         const int r = c / CPR, cc = c % CPR;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (r < rows) v = *reinterpret_cast<const u32x4*>(g + (size_t)r * ld + cc * 8);
@@ -69,35 +72,37 @@ __device__ __forceinline__ h16x8 pack8(const f32x4& a, const f32x4& b) {
 }
 
 // scores -> normalised probabilities (pn) and dropout keep-scales (ks) for this lane's query column.
-// s[t][r] is S^T at kv = 16t + 4g + r, q = 16w + (lane&15).
-template <int DH>
+// s[t][r] is S^T at kv = 16t + 4g + r, q = q0 + 16w + (lane&15).  KT = key tiles of 16 staged in Ks (4: Skv <= 64, 8: <= 128);
+// q0 = first query row of the 64-row block staged in Qs.
+template <int DH, int KT = 4>
 __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, const char* Ks, int b, int h, int w, int lane,
-                                               f32x4 (&pn)[4], f32x4 (&ks)[4]) {
+                                               f32x4 (&pn)[KT], f32x4 (&ks)[KT], int q0 = 0) {
     constexpr int PITCH = DH * 2 + 16;
     const int g = lane >> 4;
-    f32x4 s[4];
+    f32x4 s[KT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < KT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < DH / 32; ++kk) {
         const h16x8 qf = row_frag(Qs, PITCH, 16 * w, 32 * kk, lane);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s[t] = VQA_MFMA16(row_frag(Ks, PITCH, 16 * t, 32 * kk, lane), qf, s[t]);
+        for (int t = 0; t < KT; ++t) s[t] = VQA_MFMA16(row_frag(Ks, PITCH, 16 * t, 32 * kk, lane), qf, s[t]);
     }
+    const int q = q0 + 16 * w + (lane & 15);
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kv = 16 * t + 4 * g + r;
-            const bool ok = kv < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + kv]) && !(a.causal && kv > 16 * w + (lane & 15));
+            const bool ok = kv < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + kv]) && !(a.causal && kv > q);
             s[t][r] = ok ? s[t][r] * a.scale : -INFINITY;
             m = fmaxf(m, s[t][r]);
         }
     m = xor32_max(xor16_max(m));
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float e = (s[t][r] == -INFINITY) ? 0.f : __expf(s[t][r] - m);
@@ -106,46 +111,44 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
         }
     sum = xor32_sum(xor16_sum(sum));
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
-    const int q = 16 * w + (lane & 15);
     const uint64_t base = (((uint64_t)b * a.H + h) * a.Sq + q) * (uint64_t)a.Skv;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < KT; ++t) {
         pn[t] *= inv;
         ks[t] = (f32x4){1.f, 1.f, 1.f, 1.f};
     }
     if (a.drop_p > 0.f) {
         if ((a.Skv & 3) == 0) {                   // aligned groups of four keys: ONE counter hash per group (the hash is the cost)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ks[t] = dropout_scale4(a.seed, a.stream, base + 16 * t + 4 * g, a.drop_p, a.inv_keep);
+            for (int t = 0; t < KT; ++t) ks[t] = dropout_scale4(a.seed, a.stream, base + 16 * t + 4 * g, a.drop_p, a.inv_keep);
         } else {
 #pragma unroll 1
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ks[t][r] = dropout_scale(a.seed, a.stream, base + 16 * t + 4 * g + r, a.drop_p, a.inv_keep);
         }
     }
 }
 
-
-// forward of wave w (query rows 16w..16w+15) over Q, K, V staged in LDS ([64][DH] bf16, row pitch DH*2+16): scores, softmax,
-// dropout, O = P V, stored bf16 to a.o.  No barriers inside.
-template <int DH>
-__device__ __forceinline__ void attn_core_fwd(const MArgs& a, const char* Qs, const char* Ks, const char* Vs, int b, int h, int w, int lane) {
+// forward of wave w (query rows q0 + 16w .. +15) over Q (64-row block), K, V (16 KT rows) staged in LDS ([rows][DH] bf16, row pitch
+// DH*2+16): scores, softmax, dropout, O = P V, stored bf16 to a.o.  No barriers inside.
+template <int DH, int KT = 4>
+__device__ __forceinline__ void attn_core_fwd(const MArgs& a, const char* Qs, const char* Ks, const char* Vs, int b, int h, int w, int lane, int q0 = 0) {
     constexpr int PITCH = DH * 2 + 16;
     const int g = lane >> 4;
-    f32x4 pn[4], ks[4];
-    scores_softmax<DH>(a, Qs, Ks, b, h, w, lane, pn, ks);
-    h16x8 pf[2];
+    f32x4 pn[KT], ks[KT];
+    scores_softmax<DH, KT>(a, Qs, Ks, b, h, w, lane, pn, ks, q0);
+    h16x8 pf[KT / 2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) pf[u] = pack8(pn[2 * u] * ks[2 * u], pn[2 * u + 1] * ks[2 * u + 1]);
-    const int q = 16 * w + (lane & 15);
+    for (int u = 0; u < KT / 2; ++u) pf[u] = pack8(pn[2 * u] * ks[2 * u], pn[2 * u + 1] * ks[2 * u + 1]);
+    const int q = q0 + 16 * w + (lane & 15);
     // a real loop: these kernels run once per workgroup from a cold instruction cache -- measured, their run time WAS their code
     // size (fwd 1870 instructions / 8.3 us, bwd 2800 / 14 us at ~80 cycles per 64-B line); each dt iteration is independent
 #pragma unroll 1
     for (int dt = 0; dt < DH / 16; ++dt) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < KT / 2; ++u)
             o = VQA_MFMA16(col_frag(Vs, PITCH, 32 * u + 4 * g, 32 * u + 16 + 4 * g, 16 * dt, lane), pf[u], o);
         if (q < a.Sq) {
             h16x4 ob;
