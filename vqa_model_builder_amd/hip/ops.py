@@ -192,6 +192,51 @@ class _AttentionFn(torch.autograd.Function):
         return K.cast_f32(dq).view(B, Sq, D), K.cast_f32(dk).view(B, Skv, D), K.cast_f32(dv).view(B, Skv, D), None, None, None, None
 
 
+class _PackedInProjFn(torch.autograd.Function):
+    """Cross-attention in-projection through ONE packed weight: q = x_q Wq^T + bq (rows [0, D) of in_proj), k | v = x_kv Wkv^T + bkv
+    (rows [D, 3D)).  Slicing the parameter per call (``linear(query, in_proj_weight[:D])``) re-cast the weight slice to 16 bit on every
+    step (a view has no cached shadow) and made autograd assemble the packed gradient from zero-filled [3D, D] tensors; here the cached
+    shadow of the WHOLE parameter is sliced, and the two weight-gradient GEMMs write row blocks of one gradient."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, w, b):
+        D = w.shape[1]
+        q2, kv2 = xq.reshape(-1, D), xkv.reshape(-1, D)
+        Mq, Mkv = q2.shape[0], kv2.shape[0]
+        xqb, xkvb = _as_bf16(q2.contiguous()), _as_bf16(kv2.contiguous())
+        wb = shadow_of(w)
+        bq = b[:D] if b is not None else None
+        bkv = b[D:] if b is not None else None
+        q, _, _ = K.linear_fwd(xqb, wb[:D], bq, Mq, D, D, want_f32=True)
+        kv, _, _ = K.linear_fwd(xkvb, wb[D:], bkv, Mkv, 2 * D, D, want_f32=True)
+        ctx.save_for_backward(xqb, xkvb, wb)
+        ctx.meta = (xq.shape, xkv.shape, Mq, Mkv, D, b is not None)
+        return q.view(*xq.shape[:-1], D), kv.view(*xkv.shape[:-1], 2 * D)
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        xqb, xkvb, wb = ctx.saved_tensors
+        qshape, kvshape, Mq, Mkv, D, has_bias = ctx.meta
+        dqb = K.cast_bf16(dq.reshape(Mq, D).contiguous().float())
+        dkvb = K.cast_bf16(dkv.reshape(Mkv, 2 * D).contiguous().float())
+        dxq = dxkv = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxq, _ = K.linear_dx(dqb, wb[:D], Mq, D, D, want_f32=True)
+            dxq = dxq.view(qshape)
+        if ctx.needs_input_grad[1]:
+            dxkv, _ = K.linear_dx(dkvb, wb[D:], Mkv, 2 * D, D, want_f32=True)
+            dxkv = dxkv.view(kvshape)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty((3 * D, D), dtype=F32, device=dq.device)
+            K.gemm(dqb, xqb, D, D, Mq, D, D, False, False, out_f32=dw[:D], allow_split_k=True)
+            K.gemm(dkvb, xkvb, 2 * D, D, Mkv, 2 * D, D, False, False, out_f32=dw[D:], allow_split_k=True)
+        if has_bias and ctx.needs_input_grad[3]:
+            db = torch.empty((3 * D,), dtype=F32, device=dq.device)
+            K.colsum_bf16(dqb, Mq, D, out=db[:D])
+            K.colsum_bf16(dkvb, Mkv, 2 * D, out=db[D:])
+        return dxq, dxkv, dw, db
+
+
 def multi_head_attention(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, num_heads, key_padding_mask=None,
                          dropout_p=0.0, training=False, causal=False):
     """nn.MultiheadAttention (batch_first, packed in_proj), the averaged attention map it also returns is never
@@ -201,6 +246,9 @@ def multi_head_attention(query, key, value, in_proj_weight, in_proj_bias, out_w,
     if same:
         qkv = linear(query, in_proj_weight, in_proj_bias)
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    elif D % 8 == 0 and value is key:
+        q, kv = _PackedInProjFn.apply(query, key, in_proj_weight, in_proj_bias)
+        k, v = kv[..., :D], kv[..., D:]
     else:
         q = linear(query, in_proj_weight[:D], in_proj_bias[:D])
         kv = linear(key, in_proj_weight[D:], in_proj_bias[D:])
