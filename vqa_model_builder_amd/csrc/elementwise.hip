@@ -261,25 +261,40 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
         bc1 = 1.f - powf(beta1, t);
         bc2 = 1.f - powf(beta2, t);
     }
-    const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
+    const unsigned cb = blockIdx.x;      // (walking the chunks back to front, to start where the norm pass ended in the Infinity Cache: no change)
+    const VqaOptJob j = jobs[chunks[2 * cb]];
     if (j.active && j.active[0] == 0.f) return;          // expert no token was routed to: skipped like a grad-is-None parameter
     if (j.own_step) {                                    // ... and its bias corrections follow the number of updates IT received (torch keeps
         const float t = fmaxf(j.own_step[0], 1.f);       // `step` per parameter: a skipped step does not age the moments' correction)
         bc1 = 1.f - powf(beta1, t);
         bc2 = 1.f - powf(beta2, t);
     }
-    const uint64_t beg = chunks[2 * blockIdx.x + 1];
+    const uint64_t beg = chunks[2 * cb + 1];
     const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
     // prescale: the gradients in memory are SUMS over `1/prescale` data-parallel ranks; their mean is never materialised
     float gs = prescale;
     if (norm2 && max_norm > 0.f) { const float c = max_norm / (prescale * sqrtf(norm2[0]) + 1e-6f); gs = c < 1.f ? c * prescale : prescale; }
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * j.weight_decay;
     const uint64_t e4 = beg + (end - beg) / 4 * 4;
+#ifndef VQA_ADAMW_NT
+#define VQA_ADAMW_NT 1
+#endif
+#if VQA_ADAMW_NT                      // streaming hints: every byte of this pass is touched exactly once (measured: profiles/r02/adamw_variants.log)
+#define VQA_LD4(ptr) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr))
+#define VQA_ST4(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<f32x4*>(ptr))
+#else
+#define VQA_LD4(ptr) (*reinterpret_cast<const f32x4*>(ptr))
+#define VQA_ST4(ptr, val) (*reinterpret_cast<f32x4*>(ptr) = (val))
+#endif
+#ifndef VQA_ADAMW_UNROLL
+#define VQA_ADAMW_UNROLL 1
+#endif
+#pragma unroll VQA_ADAMW_UNROLL
     for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
-        f32x4 p = *reinterpret_cast<f32x4*>(j.param + i);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(j.grad + i) * gs;
-        f32x4 m = *reinterpret_cast<f32x4*>(j.exp_avg + i);
-        f32x4 v = *reinterpret_cast<f32x4*>(j.exp_avg_sq + i);
+        f32x4 p = VQA_LD4(j.param + i);
+        const f32x4 g = VQA_LD4(j.grad + i) * gs;
+        f32x4 m = VQA_LD4(j.exp_avg + i);
+        f32x4 v = VQA_LD4(j.exp_avg_sq + i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             p[k] *= decay;
@@ -287,9 +302,9 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
             v[k] = beta2 * v[k] + (1.f - beta2) * g[k] * g[k];
             p[k] -= step_size * (m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps));
         }
-        *reinterpret_cast<f32x4*>(j.param + i) = p;
-        *reinterpret_cast<f32x4*>(j.exp_avg + i) = m;
-        *reinterpret_cast<f32x4*>(j.exp_avg_sq + i) = v;
+        VQA_ST4(j.param + i, p);
+        VQA_ST4(j.exp_avg + i, m);
+        VQA_ST4(j.exp_avg_sq + i, v);
         if (j.shadow) {
             if (j.shadow_kind == 0) { h16x4 o; for (int k = 0; k < 4; ++k) o[k] = (h16_t)p[k]; *reinterpret_cast<h16x4*>((h16_t*)j.shadow + i) = o; }
             else *reinterpret_cast<f32x4*>((float*)j.shadow + i) = p;
