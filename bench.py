@@ -287,6 +287,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-ws', type=int, default=None, help='diagnostics: vqa_set_gemm_ws mode (0 = legacy tiles only, 1 = auto)')
     ap.add_argument('--fused-attn', type=int, default=None, help='diagnostics: bit 0 = fused in-projection + attention in the fusion block, bit 1 = in the encoders (default: both)')
+    ap.add_argument('--tail-runner', type=int, default=None, help='diagnostics: 0 = projection / norm / dropout / answer head as op-by-op chain instead of one node')
     ap.add_argument('--expert-runners', type=int, default=None, help='diagnostics: 0 = MoE experts as op-by-op chains (hip/ops.py) instead of the runners')
     ap.add_argument('--moe-branches', type=int, default=None, help='diagnostics: MoE experts on side streams in the captured step (0 off, 1 specialised experts, 2 every expert)')
     ap.add_argument('--group-persistent', type=int, default=None, help='diagnostics: vqa_set_gemm_group_persistent (workgroups of the grouped weight-gradient launches)')
@@ -332,6 +333,9 @@ def main():
     if args.fused_attn is not None:
         from vqa_model_builder_amd.hip import kernels as _K
         _K.FUSED_ATTENTION_FUSION, _K.FUSED_ATTENTION_ENCODERS = bool(args.fused_attn & 1), bool(args.fused_attn & 2)
+    if args.tail_runner is not None:
+        from vqa_model_builder_amd.modeling.meta_arch import vqa_model as _VM
+        _VM.TAIL_RUNNER = bool(args.tail_runner)
     if args.expert_runners is not None:
         from vqa_model_builder_amd.modeling.moe import experts as _E
         _E.EXPERT_RUNNERS = bool(args.expert_runners)

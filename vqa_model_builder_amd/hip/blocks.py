@@ -488,3 +488,91 @@ class CrossModalAttentionRunner:
         K.ln_reduce_flush()
         K.wgrad_join()
         return G, dx, dkv
+
+
+# ==================================================================================================================
+# Tail of the model: [fusion.output_proj -> LayerNorm ->] Dropout -> AnswerHead.classifier
+# reference: vqa_model.py:399-405 (projection + norm), 677 (dropout), 436-477 (classifier)
+# ==================================================================================================================
+
+class TailRunner:
+    """Issued op by op this chain is ~45 launches of 2 - 7 us (casts, one GEMM + one cast per Linear, separate bias-gradient column
+    sums, three passes for the dropout) with the launch gaps of a single dependent chain between them: profiles/r02/tail.md.  Here:
+    forward = cast, projection GEMM, LayerNorm (emitting the DROPPED bf16 operand of the classifier), one GEMM per Linear with
+    bias + ReLU + dropout in the epilogue; backward = one cast of dlogits with its column sums, one dX GEMM per Linear (ReLU' +
+    dropout mask + the next bias gradient fused), LayerNorm backward masking dy on load, all weight gradients in the grouped launch.
+
+    ``dims`` = [D, h1, .., C] of the classifier; ``pre`` = (D0, has_ln): the projection D0 -> D (and LayerNorm) in front."""
+
+    def __init__(self, W, dims, pre=None, p_in=0.0, p_hidden=0.0, eps=1e-5):
+        self.W, self.dims, self.pre, self.p_in, self.p_h, self.eps = W, list(dims), pre, p_in, p_hidden, eps
+        self.arena = GradArena(W.params)
+
+    @staticmethod
+    def covers(dims, pre=None):
+        return all(d % 8 == 0 for d in list(dims) + ([pre[0]] if pre else []))
+
+    def forward(self, x, training):
+        W, dims = self.W, self.dims
+        B = x.shape[0]
+        seed = new_seed() if training else 0
+        p0 = self.p_in if training else 0.0
+        ph = self.p_h if training else 0.0
+        S = dict(B=B, seed=seed, p0=p0, ph=ph)
+        x = x.contiguous().float()
+        if self.pre is not None:
+            D0, has_ln = self.pre
+            xb = K.cast_bf16(x)
+            S['xb'] = xb
+            if has_ln:
+                f, _, _ = K.linear_fwd(xb, W.s('proj_w'), W.p('proj_b'), B, dims[0], D0, want_f32=True)
+                _, hb, m, r = K.layernorm_fwd(f, W.p('ln.w'), W.p('ln.b'), B, dims[0], want_f32=False, want_bf16=True, eps=self.eps,
+                                              drop=Drop(p0, seed, 211))
+                S.update(f=f, m=m, r=r)
+            else:
+                _, hb, _ = K.linear_fwd(xb, W.s('proj_w'), W.p('proj_b'), B, dims[0], D0, want_bf16=True, drop=Drop(p0, seed, 211))
+        elif p0 > 0:
+            _, hb = K.dropout_f32(x, Drop(p0, seed, 211), want_f32=False, want_bf16=True)
+        else:
+            hb = K.cast_bf16(x)
+        acts, pres = [hb], []
+        n = len(dims) - 1
+        for i in range(n - 1):
+            _, hb, a = K.linear_fwd(hb, W.s(f'l{i}_w'), W.p(f'l{i}_b'), B, dims[i + 1], dims[i], want_bf16=True, want_pre=True,
+                                    act=K.ACT_RELU, drop=Drop(ph, seed, 212 + i))
+            acts.append(hb)
+            pres.append(a)
+        logits, _, _ = K.linear_fwd(hb, W.s(f'l{n - 1}_w'), W.p(f'l{n - 1}_b'), B, dims[n], dims[n - 1], want_f32=True)
+        S.update(acts=acts, pres=pres)
+        return logits, S
+
+    def backward(self, S, dlogits, need_dx=True):
+        W, dims, B, seed, p0, ph = self.W, self.dims, S['B'], S['seed'], S['p0'], S['ph']
+        n = len(dims) - 1
+        _, G = self.arena.alloc(dlogits.device)
+        acts, pres = S['acts'], S['pres']
+        d = K.rows_mask_cast(dlogits.contiguous().float(), B, dims[n], colsum=G[f'l{n - 1}_b'])
+        for i in range(n - 1, 0, -1):
+            K.linear_dw(d, acts[i], B, dims[i + 1], dims[i], out=G[f'l{i}_w'])
+            _, d = K.linear_dx(d, W.s(f'l{i}_w'), B, dims[i + 1], dims[i], want_bf16=True, act_grad_of=pres[i - 1], act_bwd=K.ACT_RELU,
+                               drop=Drop(ph, seed, 212 + i - 1), colsum=G[f'l{i - 1}_b'])
+        K.linear_dw(d, acts[0], B, dims[1], dims[0], out=G['l0_w'])
+        dx = None
+        if self.pre is None:
+            if need_dx:
+                dx, _ = K.linear_dx(d, W.s('l0_w'), B, dims[1], dims[0], want_f32=True, drop=Drop(p0, seed, 211))
+        else:
+            D0, has_ln = self.pre
+            if has_ln:
+                dh, _ = K.linear_dx(d, W.s('l0_w'), B, dims[1], dims[0], want_f32=True)
+                _, dfb, _, _ = K.layernorm_bwd(dh, S['f'], S['m'], S['r'], W.p('ln.w'), B, dims[0], want_f32=False, want_bf16=True,
+                                               drop=Drop(p0, seed, 211), drop_mode=2, dgamma=G['ln.w'], dbeta=G['ln.b'],
+                                               dx_colsum=G['proj_b'], defer=True)
+            else:
+                _, dfb = K.linear_dx(d, W.s('l0_w'), B, dims[1], dims[0], want_bf16=True, drop=Drop(p0, seed, 211), colsum=G['proj_b'])
+            K.linear_dw(dfb, S['xb'], B, dims[0], D0, out=G['proj_w'])
+            if need_dx:
+                dx, _ = K.linear_dx(dfb, W.s('proj_w'), B, dims[0], D0, want_f32=True)
+            K.ln_reduce_flush()
+        K.wgrad_join()
+        return G, dx

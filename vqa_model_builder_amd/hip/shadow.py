@@ -14,7 +14,21 @@ import torch
 from . import kernels as K
 
 
+# A fused optimiser updates parameters through raw pointers (no autograd version bump) and writes the bf16 copy of ONE set per
+# parameter itself; it then bumps the generation and stamps the sets it kept current.  A set that shares a parameter with the stamped
+# one (the same Linear reached through two different nodes) sees the generation move on and re-casts at its next use.
+_generation = 0
+
+
+def bump_generation() -> int:
+    global _generation
+    _generation += 1
+    return _generation
+
+
 class ShadowSet:
+    _uses = 0
+
     def __init__(self):
         self._plan: List[Tuple[str, torch.nn.Parameter, str, int, int]] = []   # (key, param, arena, offset, numel)
         self._views: Dict[str, Tuple[str, int, Tuple[int, ...]]] = {}          # key -> (arena, offset, shape)
@@ -23,7 +37,8 @@ class ShadowSet:
         self._jobs = None
         self._sig = None
         self._max_n = 0
-        self.fresh_token = None           # set by a fused optimiser that wrote the bf16 arena itself
+        self._gen = 0                     # generation (above) at which the arenas were last known current
+        self.last_use = 0                 # ordinal of the latest refresh(): the optimiser keeps the most recently used set current
 
     # -- planning (construction time, device-agnostic) --------------------------------------------------------
     def _reserve(self, arena: str, numel: int) -> int:
@@ -69,10 +84,12 @@ class ShadowSet:
                     raise RuntimeError(f'parameter on {p.device}, expected {device}: move the module to the GPU first')
             self._materialise(device)
             self._sig = None
+        ShadowSet._uses += 1
+        self.last_use = ShadowSet._uses
         sig = tuple(p._version for _, p, _, _, _ in self._plan)
-        if sig != self._sig:
+        if sig != self._sig or self._gen != _generation:
             K.cast_multi(self._jobs, len(self._plan), self._max_n)
-            self._sig = sig
+            self._sig, self._gen = sig, _generation
 
     def get(self, key: str) -> torch.Tensor:
         arena, off, shape = self._views[key]

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ...hip import ops
-from ...hip.blocks import CrossModalAttentionRunner
+from ...hip.blocks import CrossModalAttentionRunner, TailRunner
 from ...hip.kernels import ACT_NONE, ACT_RELU, Drop
 from ...hip.kernels import skip_weight_grads as K_skip
 from .backbones import ClipVisionBackbone, RobertaBackbone, _BlockFn, _Weights, _flatten_param_keys, _require_cuda, _split_grads
@@ -266,13 +266,17 @@ class MultimodalFusion(nn.Module):
     def _cls(x):
         return x[:, 0, :] if x.dim() == 3 else x
 
-    def forward(self, visual_features, text_features, visual_mask=None, text_mask=None):
+    def forward(self, visual_features, text_features, visual_mask=None, text_mask=None, project=True):
+        """``project=False`` (not in the reference signature; cross_attention only): returns token 0 of the last fusion layer [B, D]
+        BEFORE output_proj / layer_norm -- the model's tail node (_Tail) runs those together with the dropout and the answer head."""
         ft = self.config.fusion_type
         if ft == 'cross_attention':
             last = len(self.fusion_layers) - 1
             for i, layer in enumerate(self.fusion_layers):
                 # only token 0 of the last layer's output is read below: that layer computes just what token 0 depends on
                 text_features = layer(text_features, visual_features, text_mask, visual_mask, first_token_only=(i == last))
+            if not project:
+                return text_features[:, 0, :]
             fused = ops.linear(text_features[:, 0, :], self.output_proj.weight, self.output_proj.bias)
         elif ft == 'concat':
             combined = torch.cat([self._cls(visual_features), self._cls(text_features)], dim=-1)
@@ -288,6 +292,66 @@ class MultimodalFusion(nn.Module):
         if self.layer_norm is not None:
             fused = ops.layer_norm(fused, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         return fused
+
+
+# True: the chain behind the last fusion layer runs as ONE autograd node (hip.blocks.TailRunner) where its shapes allow.  False: the
+# op-by-op chain (what the runner is tested against).
+TAIL_RUNNER = True
+
+
+class _Tail:
+    """Owner of the tail node: [fusion.output_proj -> fusion.layer_norm ->] model.dropout -> answer_head.classifier.  Not a Module:
+    it only REFERENCES the parameters (names / state_dict stay the reference's)."""
+
+    def __init__(self, model, with_projection, with_dropout):
+        head, fusion = model.answer_head, model.fusion
+        lins = [m for m in head.classifier if isinstance(m, nn.Linear)]
+        self.model, self.dims = model, [lins[0].in_features] + [l.out_features for l in lins]
+        W = _Weights()
+        pre, eps = None, 1e-5
+        if with_projection:
+            W.params['proj_w'], W.params['proj_b'] = fusion.output_proj.weight, fusion.output_proj.bias
+            W.shadows.add('proj_w', fusion.output_proj.weight, tuple(fusion.output_proj.weight.shape))
+            if fusion.layer_norm is not None:
+                W.params['ln.w'], W.params['ln.b'] = fusion.layer_norm.weight, fusion.layer_norm.bias
+                eps = fusion.layer_norm.eps
+            pre = (fusion.output_proj.in_features, fusion.layer_norm is not None)
+        for i, lin in enumerate(lins):
+            W.params[f'l{i}_w'], W.params[f'l{i}_b'] = lin.weight, lin.bias
+            W.shadows.add(f'l{i}_w', lin.weight, tuple(lin.weight.shape))
+        self._W, self.pre = W, pre
+        self._flat = _flatten_param_keys(W.params)
+        self._runner = TailRunner(W, self.dims, pre, model.dropout.p if with_dropout else 0.0, head.config.dropout, eps)
+
+        self._with_dropout = with_dropout
+        self._sources = lins + ([fusion.output_proj, fusion.layer_norm] if with_projection else [])
+
+    def covers(self):
+        return TailRunner.covers(self.dims, self.pre)
+
+    def current(self):
+        """Still describes the model: nobody swapped a module or re-assigned a parameter since this tail was built."""
+        model = self.model
+        lins = [m for m in model.answer_head.classifier if isinstance(m, nn.Linear)]
+        now = lins + ([model.fusion.output_proj, model.fusion.layer_norm] if self.pre is not None else [])
+        if len(now) != len(self._sources) or any(a is not b for a, b in zip(now, self._sources)):
+            return False
+        live = {id(p) for m in now if m is not None for p in m.parameters(recurse=False)}
+        return all(id(p) in live for _, p in self._flat)
+
+    def _hip_forward(self, x):
+        self._W.shadows.refresh(x.device)
+        self._runner.p_in = self.model.dropout.p if self._with_dropout else 0.0
+        self._runner.p_h = self.model.answer_head.config.dropout
+        return self._runner.forward(x, self.model.training)
+
+    def _hip_backward(self, saved, dout, needs):
+        with K_skip(not any(p.requires_grad for _, p in self._flat)):
+            G, dx = self._runner.backward(saved, dout, need_dx=needs[0])
+        return [dx], _split_grads(self._flat, G)
+
+    def __call__(self, x):
+        return _BlockFn.apply(self, 1, x, *[p for _, p in self._flat])
 
 
 class AnswerHead(nn.Module):
@@ -398,7 +462,15 @@ class VietnameseVQAModel(nn.Module):
         A method of its own so that the data-parallel captured step (graph.GraphedTrainStep) can cut the autograd graph at the
         encoder outputs: head / fusion backward, text backward and vision backward become separate HIP graphs, and each block's
         gradient all-reduce travels while the next block's backward computes."""
-        fused = self.fusion(visual_spatial, text_sequence, text_mask=~attention_mask.bool())
+        text_mask = ~attention_mask.bool()
+        whole = (TAIL_RUNNER and not return_features and self.moe_layer is None and self.config.fusion.fusion_type == 'cross_attention'
+                 and text_sequence.is_cuda)
+        if whole:
+            tail = self._tail(True, True)
+            if tail.covers():
+                logits = tail(self.fusion(visual_spatial, text_sequence, text_mask=text_mask, project=False))
+                return self._finish(logits, labels, None, None, None, None)
+        fused = self.fusion(visual_spatial, text_sequence, text_mask=text_mask)
         moe_info = None
         if self.moe_layer is not None:
             if fused.dim() == 2:
@@ -411,18 +483,34 @@ class VietnameseVQAModel(nn.Module):
             else:
                 moe_output = self.moe_layer(fused)
                 fused, moe_info = moe_output if isinstance(moe_output, tuple) else (moe_output, None)
-        fused = ops.dropout(fused, self.dropout.p, self.training)
-        logits = self.answer_head(fused)
+        tail = self._tail(False, not return_features) if (TAIL_RUNNER and fused.is_cuda and fused.dim() == 2) else None
+        if tail is not None and tail.covers():
+            if return_features:                 # the dropped features are an output: that dropout stays an op of its own
+                fused = ops.dropout(fused, self.dropout.p, self.training)
+            logits = tail(fused)
+        else:
+            fused = ops.dropout(fused, self.dropout.p, self.training)
+            logits = self.answer_head(fused)
+        if return_features:
+            return self._finish(logits, labels, visual_pooled, text_pooled, fused, moe_info)
+        return self._finish(logits, labels, None, None, None, moe_info)
+
+    def _tail(self, with_projection, with_dropout):
+        tails = self.__dict__.setdefault('_tails', {})
+        key = (with_projection, with_dropout)
+        if key not in tails or not tails[key].current():
+            tails[key] = _Tail(self, with_projection, with_dropout)
+        return tails[key]
+
+    @staticmethod
+    def _finish(logits, labels, visual, text, fused, moe_info):
         loss = None
         if labels is not None:
             loss, predictions = ops.cross_entropy_argmax(logits, labels)
         else:
             predictions = ops.argmax(logits)
-        return VQAOutput(logits=logits, loss=loss, predictions=predictions,
-                         visual_features=visual_pooled if return_features else None,
-                         text_features=text_pooled if return_features else None,
-                         fused_features=fused if return_features else None,
-                         knowledge_features=None, moe_info=moe_info)
+        return VQAOutput(logits=logits, loss=loss, predictions=predictions, visual_features=visual, text_features=text,
+                         fused_features=fused, knowledge_features=None, moe_info=moe_info)
 
 
 def create_vqa_model(config: Optional[VQAModelConfig] = None, **kwargs) -> VietnameseVQAModel:

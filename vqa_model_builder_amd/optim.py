@@ -15,6 +15,7 @@ import torch
 
 from .hip import kernels as K
 from .hip import ops as _ops
+from .hip import shadow as _shadow
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -43,6 +44,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def attach_shadows(self, model):
         """Lets the update kernel write the bf16 / packed-fp32 weight shadows of the block runners directly."""
         self._shadow_sets = [m._W.shadows for m in model.modules() if hasattr(m, '_W')]
+        # nodes built lazily at the first forward (the model's tail: vqa_model._Tail) hang off their host module's ``_tails``
+        self._tail_hosts = [m for m in model.modules() if hasattr(type(m), '_tail')]
         return self
 
     def make_capturable(self, device):
@@ -108,13 +111,13 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _shadow_map(self):
         out = {}
-        for ss in self._shadow_sets:
-            if ss._jobs is None:
-                continue                                   # not materialised yet (no forward so far): torch-side refresh will do it
+        lazy = [t._W.shadows for h in getattr(self, '_tail_hosts', ()) for t in h.__dict__.get('_tails', {}).values()]
+        sets = [ss for ss in self._shadow_sets + lazy if ss._jobs is not None]   # others: not materialised yet, their first refresh casts
+        for ss in sorted(sets, key=lambda ss: ss.last_use):                      # a parameter in two sets: the most recently used one wins
             for _, p, arena, off, _n in ss._plan:
                 t = ss._arena[arena]
-                out[id(p)] = (t.data_ptr() + off * t.element_size(), 0 if arena == 'bf16' else 1)
-        return out
+                out[id(p)] = (t.data_ptr() + off * t.element_size(), 0 if arena == 'bf16' else 1, ss)
+        return out, sets
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -125,7 +128,8 @@ class FusedAdamW(torch.optim.Optimizer):
             first = next((p for g in self.param_groups for p in g['params'] if p.grad is not None), None)
             if first is not None:
                 self.make_capturable(first.device)
-        shadows = self._shadow_map()
+        shadows, shadow_sets = self._shadow_map()
+        updated = set()
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
         counted = {}                                    # MoE layers under dense dispatch: id(steps) -> (active [E], steps [E], {expert: step so far})
         standalone = []
@@ -144,7 +148,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 prev_step = int(state['step'])
                 if self._hyper is None:                     # capturable mode counts on the device (bias corrections come from there)
                     state['step'] = prev_step + 1
-                sp, sk = shadows.get(id(p), (0, 0))
+                sp, sk, _ = shadows.get(id(p), (0, 0, None))
+                updated.add(id(p))
                 if sp == 0:                                 # stand-alone parameter (tail ops, experts): its cached bf16 copy, if any
                     sh = _ops.standalone_shadow(p)
                     if sh is not None and sh.numel() == p.numel():
@@ -225,6 +230,10 @@ class FusedAdamW(torch.optim.Optimizer):
             else:                                           # static scale: only record found_inf
                 K._chk(lib.vqa_amp_update(amp.data_ptr(), self._norm2.data_ptr(), 1.0, 1.0, 1 << 30, st), 'vqa_amp_update')
         _ops.bump_shadow_generation()                      # stand-alone bf16 shadows this step did not write are stale now
+        gen = _shadow.bump_generation()
+        for ss in shadow_sets:                             # sets whose every updated parameter was written here stay current
+            if all(id(p) not in updated or shadows[id(p)][2] is ss for _, p, _, _, _ in ss._plan):
+                ss._gen = gen
         for p in standalone:
             _ops.mark_shadow_fresh(p)
         return loss
