@@ -234,7 +234,9 @@ def _ref_attn(q, k, v, B, H, Sq, Skv, Dh, mask):
                                                   (2, 8, 100, 100, 256, False), (2, 8, 100, 1, 256, False), (2, 8, 1, 100, 256, True),
                                                   # 65 - 128 keys on the MFMA kernels (8 key tiles): the generative model's 114-token memory
                                                   (2, 8, 64, 114, 96, True), (2, 8, 33, 114, 96, False), (2, 8, 114, 114, 96, True), (3, 4, 17, 100, 32, False),
-                                                  (2, 2, 64, 128, 128, True), (2, 12, 50, 65, 64, False)])
+                                                  (2, 2, 64, 128, 128, True), (2, 12, 50, 65, 64, False),
+                                                  # two 64-row query blocks inside the backward workgroup (dK / dV summed over the blocks)
+                                                  (2, 4, 128, 128, 64, True), (2, 8, 65, 114, 96, False), (2, 2, 127, 40, 128, False)])
 def test_attention_fwd_bwd(B, H, Sq, Skv, Dh, masked):
     D = H * Dh
     # packed layouts with non-trivial leading dims: q in [.., 3D] at col 0, k/v in a [.., 2D] buffer
@@ -322,7 +324,7 @@ def test_fused_inproj_attention_rejects_uncovered_shapes():
         K.fused_inproj_attention_fwd(x, x, w, None, B, H, S, S, D)
 
 
-@pytest.mark.parametrize('B,H,Sq,Skv,Dh', [(3, 4, 16, 16, 32), (2, 8, 33, 33, 96), (2, 2, 100, 100, 64)])
+@pytest.mark.parametrize('B,H,Sq,Skv,Dh', [(3, 4, 16, 16, 32), (2, 8, 33, 33, 96), (2, 2, 100, 100, 64), (2, 4, 128, 128, 96)])
 def test_causal_attention_fwd_bwd(B, H, Sq, Skv, Dh):
     """``causal`` (nn.TransformerDecoder's tgt_mask, generative_vqa_model.py:447-451) in the MFMA and the generic kernel, with a key
     padding mask on top: against torch's masked softmax, forward and the three gradients."""
@@ -722,10 +724,39 @@ def test_layernorm_backward_deferred_grouped_reduce_and_accumulate_mode():
                 assert torch.allclose(a[i], b[i], atol=2e-3, rtol=1e-4), (mode, i)
 
 
+@pytest.mark.parametrize('B,H,Sq,Skv,Dh,causal', [(2, 8, 114, 114, 96, False), (2, 4, 128, 100, 64, False), (2, 4, 128, 128, 32, True), (3, 8, 40, 114, 96, False)])
+def test_attention_mfma_and_generic_kernels_draw_the_same_dropout_masks(B, H, Sq, Skv, Dh, causal):
+    """Forward and backward of one attention site may run on different kernels (MFMA: <= 128 keys and queries; generic: anything):
+    with dropout 0.2 both must key the mask on ((b, h, q), kv) alike -- second 64-row query block of the MFMA backward included --
+    so outputs and the three gradients agree to bf16 rounding, not to a 20 % mask mismatch."""
+    from vqa_model_builder_amd.hip.lib import load
+    D = H * Dh
+    q, k, v = [rnd((B * s, D), i).to(DEV).to(BF) for i, s in ((1, Sq), (2, Skv), (3, Skv))]
+    do = rnd((B * Sq, D), 4).to(DEV).to(BF)
+    mask = torch.zeros((B, Skv), dtype=torch.uint8, device=DEV)
+    mask[0, Skv - 3:] = 1
+    d = K.Drop(0.2, 4242, 9)
+    res = {}
+    try:
+        for on in (1, 0):
+            load().vqa_set_attention_mfma(on)
+            o = K.attention_fwd(q, k, v, D, D, D, B, H, Sq, Skv, Dh, mask, d, causal=causal)
+            dq = torch.empty((B * Sq, D), dtype=BF, device=DEV)
+            dk, dv = torch.empty((B * Skv, D), dtype=BF, device=DEV), torch.empty((B * Skv, D), dtype=BF, device=DEV)
+            K.attention_bwd(q, k, v, do, D, D, D, B, H, Sq, Skv, Dh, dq, dk, dv, D, D, D, mask, d, causal=causal)
+            torch.cuda.synchronize()
+            res[on] = (o, dq, dk, dv)
+    finally:
+        load().vqa_set_attention_mfma(1)
+    for a, b in zip(res[1], res[0]):
+        err = (a.float() - b.float()).abs().max().item() / (b.float().abs().max().item() + 1e-6)
+        assert err < 2e-2, err
+
+
 def test_attention_backward_fused_bias_gradient_sums():
     """dq/dk/dv column sums accumulated by the attention backward (MFMA kernel: per-workgroup LDS reduction + one atomic per
     column; generic kernel: separate passes) == column sums of the bf16 gradients it wrote."""
-    for (B, H, Sq, Skv, Dh) in [(4, 12, 50, 50, 64), (3, 8, 64, 40, 96), (2, 4, 100, 100, 32), (2, 8, 40, 114, 96), (2, 4, 64, 128, 64)]:
+    for (B, H, Sq, Skv, Dh) in [(4, 12, 50, 50, 64), (3, 8, 64, 40, 96), (2, 4, 100, 100, 32), (2, 8, 40, 114, 96), (2, 4, 64, 128, 64), (2, 8, 114, 114, 96)]:
         D = H * Dh
         q, k, v = [rnd((B * s, D), i).to(DEV).to(BF) for i, s in ((1, Sq), (2, Skv), (3, Skv))]
         do = rnd((B * Sq, D), 4).to(DEV).to(BF)

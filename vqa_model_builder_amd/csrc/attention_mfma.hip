@@ -48,15 +48,24 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
     const bool want_cs = a.dq_cs || a.dk_cs || a.dv_cs;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
-    stage_tile<DH>(Qs, a.q + (size_t)b * a.Sq * a.ldq + h * DH, a.Sq, a.ldq, tid);
     stage_tile<DH, KR>(Ks, a.k + (size_t)b * a.Skv * a.ldk + h * DH, a.Skv, a.ldk, tid);
     stage_tile<DH, KR>(Vs, a.v + (size_t)b * a.Skv * a.ldv + h * DH, a.Skv, a.ldv, tid);
-    stage_tile<DH>(Gs, a.d_o + (size_t)b * a.Sq * a.ldd_o + h * DH, a.Sq, a.ldd_o, tid);
+    // Query blocks of 64 rows, one after the other (Sq <= 128: the generative model's 114-token fusion encoder).  dQ rows belong to one
+    // block; dK / dV sum over the blocks: block 0 stores its bf16 partial, the next block's SAME thread reads it back, adds in fp32 and
+    // stores the total (a thread's own store -> load to one address is ordered; no other thread touches it).
+    const int nqb = (a.Sq + 63) / 64;
+#pragma unroll 1
+    for (int qb = 0; qb < nqb; ++qb) {
+    const int q0 = 64 * qb, qrows = min(64, a.Sq - q0);
+    const bool last_qb = qb == nqb - 1;
+    if (qb > 0) __syncthreads();                                   // phase 2 of the previous block still reads Qs / Gs / Pt / Dt
+    stage_tile<DH>(Qs, a.q + ((size_t)b * a.Sq + q0) * a.ldq + h * DH, qrows, a.ldq, tid);
+    stage_tile<DH>(Gs, a.d_o + ((size_t)b * a.Sq + q0) * a.ldd_o + h * DH, qrows, a.ldd_o, tid);
     __syncthreads();
     // ---- phase 1: this wave's 16 query rows
     {
         f32x4 pn[KT], ks[KT], dp[KT];
-        scores_softmax<DH, KT>(a, Qs, Ks, b, h, w, lane, pn, ks);
+        scores_softmax<DH, KT>(a, Qs, Ks, b, h, w, lane, pn, ks, q0);
 #pragma unroll
         for (int t = 0; t < KT; ++t) dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { dp[t][r] *= ks[t][r]; delta += pn[t][r] * dp[t][r]; }
         delta = xor32_sum(xor16_sum(delta));
-        const int q = 16 * w + i;
+        const int ql = 16 * w + i, q = q0 + ql;                      // row inside the block (tile index) | row of the sample
         const bool qok = q < a.Sq;
 #pragma unroll
         for (int t = 0; t < KT; ++t)
@@ -81,8 +90,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
                 const float pd = qok ? pn[t][r] * ks[t][r] : 0.f;
                 dp[t][r] = ds;                                         // dp now holds dS^T
                 const int kv = 16 * t + 4 * g + r;
-                *reinterpret_cast<h16_t*>(Pt + kv * PT + q * 2) = (h16_t)pd;
-                *reinterpret_cast<h16_t*>(Dt + kv * PT + q * 2) = (h16_t)ds;
+                *reinterpret_cast<h16_t*>(Pt + kv * PT + ql * 2) = (h16_t)pd;
+                *reinterpret_cast<h16_t*>(Dt + kv * PT + ql * 2) = (h16_t)ds;
             }
         // dQ^T = K^T dS^T, dS^T straight from the accumulator registers
         h16x8 df[KT / 2];
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) ob[r] = (h16_t)o[r];
             if (qok) *reinterpret_cast<h16x4*>(a.dq + ((size_t)b * a.Sq + q) * a.lddq + h * DH + 16 * dt + 4 * g) = ob;
-            if (want_cs) slab_colsum(&cs_part[0][w][16 * dt + 4 * g], ob, qok, lane);
+            if (want_cs) slab_colsum(&cs_part[0][w][16 * dt + 4 * g], ob, qok, lane, qb > 0);
         }
     }
     __syncthreads();
@@ -119,17 +128,25 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
             ok = VQA_MFMA16(col_frag(Qs, PITCH, 32 * u + 8 * g, 32 * u + 8 * g + 4, 16 * dt, lane), sf, ok);
         }
         h16x4 bv, bk;
+        h16_t* pdv = a.dv + ((size_t)b * a.Skv + kv) * a.lddv + h * DH + 16 * dt + 4 * g;
+        h16_t* pdk = a.dk + ((size_t)b * a.Skv + kv) * a.lddk + h * DH + 16 * dt + 4 * g;
+        if (qb > 0 && kok) {
+            const h16x4 pv = *reinterpret_cast<const h16x4*>(pdv), pk = *reinterpret_cast<const h16x4*>(pdk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ov[r] += (float)pv[r]; ok[r] += (float)pk[r]; }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { bv[r] = (h16_t)ov[r]; bk[r] = (h16_t)ok[r]; }
         if (kok) {
-            *reinterpret_cast<h16x4*>(a.dv + ((size_t)b * a.Skv + kv) * a.lddv + h * DH + 16 * dt + 4 * g) = bv;
-            *reinterpret_cast<h16x4*>(a.dk + ((size_t)b * a.Skv + kv) * a.lddk + h * DH + 16 * dt + 4 * g) = bk;
+            *reinterpret_cast<h16x4*>(pdv) = bv;
+            *reinterpret_cast<h16x4*>(pdk) = bk;
         }
-        if (want_cs) {
+        if (want_cs && last_qb) {                                   // column sums of the FINAL stored values
             slab_colsum(&cs_part[1][w][16 * dt + 4 * g], bk, kok, lane, kp > 0);
             slab_colsum(&cs_part[2][w][16 * dt + 4 * g], bv, kok, lane, kp > 0);
         }
     }
+    }   // query blocks
     if (want_cs) {
         __syncthreads();
         for (int c = tid; c < 3 * DH; c += 256) {
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MArgs a_in) {
 }
 
 bool fill(const VqaAttnDesc* d, MArgs& a, bool bwd) {
-    if (d->Sq < 1 || d->Skv < 1 || d->Skv > 128 || d->Sq > (bwd ? 64 : 128)) return false;       // backward: one 64-row query block
+    if (d->Sq < 1 || d->Skv < 1 || d->Skv > 128 || d->Sq > 128) return false;      // forward: query blocks over gridDim.y; backward: inside the workgroup
     if (d->Dh != 32 && d->Dh != 64 && d->Dh != 96 && d->Dh != 128) return false;
     if ((d->ldq | d->ldk | d->ldv | d->ldo) % 8) return false;
     if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return false;
