@@ -258,6 +258,11 @@ int vqa_moe_combine_bwd(const float* dout, const float* y, const int32_t* list, 
 /* dweights[t,k] = dw_all[indices[t,k], t] */
 int vqa_moe_route_weight_grad(const float* dw_all, const int64_t* indices, float* dweights, int T, int E, int K, vqa_stream_t s);
 
+/* GatedLinearExpert's gate (reference src/modeling/moe/expert_types.py:501-504: h, gate = fc1(x).chunk(2); h * sigmoid(gate); dropout):
+ * y[t,j] = drop(h[t,j] * sigmoid(h[t,H+j])) over h [T,2H] fp32 (dropout keyed on t*H+j), and its backward dh [T,2H]. */
+int vqa_glu_fwd(const float* h, float* y, int T, int H, float drop_p, uint64_t drop_seed, uint32_t drop_stream, vqa_stream_t s);
+int vqa_glu_bwd(const float* dy, const float* h, float* dh, int T, int H, float drop_p, uint64_t drop_seed, uint32_t drop_stream, vqa_stream_t s);
+
 /* Dense dispatch (captured-graph mode, moe_layer.py:151-168 exactly as the reference runs it: every expert on every token, combined
  * with weights that are 0 where an expert was not chosen): out[t,:] = sum_e w_all[e,t] * ys[e][t,:] in one launch (w_all [E,T] as
  * vqa_moe_expert_tokens writes it), and its backward dys[e][t,:] = w_all[e,t] * dout[t,:], dw_all[e,t] = <dout[t,:], ys[e][t,:]>.

@@ -1,7 +1,7 @@
 """Golden-vector generator.  Runs ONLY in the build container, where /root/reference is importable.
 
     mkdir -p /tmp/golden_cwd && cd /tmp/golden_cwd && \
-    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts|generative|fusion]
+    PYTHONPATH=/root/reference:/root/repo python3 -B /root/repo/oracle/gen_golden.py [--only tiny|full|full32|parts|moe_variants|generative|fusion]
 
 It imports the reference's own ``src.modeling.meta_arch`` / ``src.modeling.moe`` modules (SURVEY.md
 §8c, Appendix C), replaces only the two hub-NAME loaders by local random-weight construction of the
@@ -532,6 +532,49 @@ def run_fusion_case(tag, case, seed):
     print(f'[gen_golden] {tag}: |out|={float(out0.norm()):.4f} params={sum(p.numel() for p in model.parameters())} -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
 
 
+def run_moe_variants(seed=17):
+    """The reference's other MoE layers (moe_layer.py:199-358 SparseMOELayer with the capacity cut active, :361-548 HierarchicalMOE) and
+    the GLU expert (expert_types.py:448-515) in eval mode: output, input gradient, load-balance loss, every parameter gradient."""
+    from src.modeling.moe.moe_layer import HierarchicalMOE, SparseMOELayer
+    arrays, meta = {}, {'seed': seed, 'cases': {}}
+    D, Hm = 64, 128
+    cases = {
+        'sparse_ff.': (lambda: SparseMOELayer(input_dim=D, hidden_dim=Hm, output_dim=D, num_experts=4, top_k=2, capacity_factor=0.6,
+                                               dropout=0.1, expert_type='feedforward'), (3, 10, D)),
+        'sparse_glu.': (lambda: SparseMOELayer(input_dim=D, hidden_dim=Hm, output_dim=D, num_experts=4, top_k=2, capacity_factor=1.25,
+                                                dropout=0.1, expert_type='glu'), (3, 10, D)),
+        'hier.': (lambda: HierarchicalMOE(input_dim=D, hidden_dim=Hm, output_dim=D, num_expert_groups=4, experts_per_group=2,
+                                           top_k_groups=2, top_k_experts=1, dropout=0.1), (3, 5, D)),
+    }
+    for prefix, (make, xshape) in cases.items():
+        layer = make().eval()
+        shapes = {prefix + k: tuple(v.shape) for k, v in layer.state_dict().items()}
+        sd = dw.make_state_dict(shapes, seed)
+        layer.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+        meta['cases'][prefix] = {'shapes': {k: list(v) for k, v in shapes.items()}, 'x': list(xshape)}
+        x = dw.normal(prefix + 'x', xshape, seed).requires_grad_(True)
+        gy = dw.normal(prefix + 'gy', xshape, seed + 1)
+        with torch.enable_grad():
+            y = layer(x)
+            (y * gy).sum().backward()
+        arrays[prefix + 'out'] = y.detach().numpy()
+        arrays[prefix + 'dx'] = x.grad.numpy()
+        arrays[prefix + 'aux'] = np.float64(float(layer.get_aux_loss()))
+        if prefix.startswith('sparse'):
+            T = xshape[0] * xshape[1]
+            arrays[prefix + 'capacity'] = np.int64(layer._compute_capacity(T))
+            idx = layer.aux_outputs.get('expert_indices')
+        for n, p in layer.named_parameters():
+            if p.grad is not None:
+                arrays[prefix + 'g/' + n] = p.grad.numpy().copy()
+        print(f'[gen_golden] moe_variants {prefix}: |out|={float(y.norm()):.4f} aux={float(layer.get_aux_loss()):.5f} '
+              f'grads={sum(p.grad is not None for p in layer.parameters())}/{sum(1 for _ in layer.parameters())}')
+    arrays['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, 'moe_variants.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'[gen_golden] moe_variants -> {path} ({os.path.getsize(path) / 1e3:.0f} kB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='all')
@@ -541,6 +584,8 @@ def main():
     torch.set_num_threads(os.cpu_count())
     if args.only in ('all', 'parts'):
         run_parts()
+    if args.only in ('all', 'moe_variants'):
+        run_moe_variants()
     if args.only in ('all', 'tiny'):
         run_model_case('tiny_concat', TINY, 'concat', 0, 11, True, relu_margin=1e-2)
         run_model_case('tiny_xattn', TINY, 'cross_attention', 0, 12, True, relu_margin=1e-2)

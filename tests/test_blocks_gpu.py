@@ -382,6 +382,53 @@ def test_answer_head_and_loss(D, hidden, C, B):
     check_grads(head, lv, 'h.', tol=2 * GRAD_TOL)
 
 
+@pytest.mark.parametrize('prefix', ['sparse_ff.', 'sparse_glu.', 'hier.'])
+def test_sparse_and_hierarchical_moe_match_the_reference(prefix):
+    """SparseMOELayer (capacity cut active: 0.6 x 30 x 2 / 4 = 9 tokens per expert against ~15 routed), the same layer over GLU experts
+    and HierarchicalMOE (4 groups x 2 experts: vision / text / multimodal / feed-forward at S = 5) against outputs of the reference
+    itself (tests/golden/moe_variants.npz, oracle/gen_golden.py --only moe_variants): output, input gradient, load-balance loss, every
+    parameter gradient; parameters the reference leaves without a gradient (unrouted experts) get none here."""
+    from tests.conftest import load_golden
+    from vqa_model_builder_amd.modeling.moe import HierarchicalMOE, SparseMOELayer
+    arrays, meta = load_golden('moe_variants')
+    seed, case = meta['seed'], meta['cases'][prefix]
+    D, Hm = 64, 128
+    if prefix == 'hier.':
+        layer = HierarchicalMOE(input_dim=D, hidden_dim=Hm, output_dim=D, num_expert_groups=4, experts_per_group=2, top_k_groups=2, top_k_experts=1,
+                                dropout=0.1)
+    else:
+        layer = SparseMOELayer(input_dim=D, hidden_dim=Hm, output_dim=D, num_experts=4, top_k=2, capacity_factor=0.6 if prefix == 'sparse_ff.' else 1.25,
+                               dropout=0.1, expert_type='feedforward' if prefix == 'sparse_ff.' else 'glu')
+    shapes = {k: tuple(v) for k, v in case['shapes'].items()}
+    assert {prefix + k for k in layer.state_dict()} == set(shapes)
+    sd = dw.make_state_dict(shapes, seed)
+    layer.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    layer = layer.to(DEV).eval()
+    if prefix == 'sparse_ff.':
+        assert layer._compute_capacity(30) == int(arrays[prefix + 'capacity']) == 9
+    x = dw.normal(prefix + 'x', tuple(case['x']), seed).to(DEV).requires_grad_(True)
+    gy = dw.normal(prefix + 'gy', tuple(case['x']), seed + 1).to(DEV)
+    y = layer(x)
+    (y * gy).sum().backward()
+    t = lambda k: torch.from_numpy(np.asarray(arrays[prefix + k]))
+    assert rl(y, t('out')) <= OUT_TOL, rl(y, t('out'))
+    assert rl(x.grad, t('dx')) <= 2 * GRAD_TOL, rl(x.grad, t('dx'))
+    assert abs(float(layer.get_aux_loss()) - float(arrays[prefix + 'aux'])) <= 1e-5
+    refs = {k[len(prefix) + 2:]: torch.from_numpy(np.asarray(v)) for k, v in arrays.items() if k.startswith(prefix + 'g/')}
+    gmax = max(float(g.norm()) for g in refs.values())
+    worst = (0.0, '')
+    for n, p in layer.named_parameters():
+        ref = refs.get(n)
+        if ref is None or float(ref.norm()) < 1e-4 * gmax:
+            assert p.grad is None or float(p.grad.norm()) <= 1e-2 * gmax, n
+            continue
+        assert p.grad is not None, n
+        e = rl(p.grad, ref)
+        worst = max(worst, (e, n))
+        assert e <= 2 * GRAD_TOL, (n, e)
+    print('moe variant', prefix, 'out', rl(y, t('out')), 'dx', rl(x.grad, t('dx')), 'worst grad', worst)
+
+
 class _TailHost(torch.nn.Module):
     """The three attributes vqa_model._Tail reads off the model (fusion.output_proj / layer_norm, dropout, answer_head)."""
 

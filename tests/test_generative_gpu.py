@@ -153,3 +153,111 @@ def test_standalone_cross_attention_fusion_matches_the_reference(tag, mode):
         assert agg <= ENV_GRAD * ref_agg and max(e_dv, e_dt) <= 4 * ENV_GRAD * max(ref_agg, env), (agg, ref_agg, e_dv, e_dt)
     finally:
         vqa.set_compute_dtype('bf16')
+
+
+def _layer_case(kind, D, H, F, B, S, A):
+    from vqa_model_builder_amd.modeling.meta_arch import generative_vqa_model as gm
+    torch.manual_seed(5)
+    if kind == 'encoder':
+        layer = gm._EncoderLayer(D, H, F, 0.1)
+    else:
+        layer = gm._DecoderLayer(D, H, F, 0.1)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_uniform_(p)
+            else:
+                p.normal_(0.0, 0.05)
+        for n in (layer.norm1, layer.norm2):
+            n.weight.add_(1.0)
+        if kind == 'decoder':
+            layer.norm3.weight.add_(1.0)
+    layer = layer.to(DEV)
+    mem = dw.normal('mem', (B, S, D), 51).to(DEV)
+    mem_mask = torch.zeros((B, S), dtype=torch.bool, device=DEV)
+    mem_mask[0, S - 7:] = True
+    if kind == 'encoder':
+        return layer, (mem,), dict(src_key_padding_mask=mem_mask), dw.normal('gy', (B, S, D), 52).to(DEV)
+    tgt = dw.normal('tgt', (B, A, D), 53).to(DEV)
+    tgt_mask = torch.zeros((B, A), dtype=torch.bool, device=DEV)
+    tgt_mask[-1, A - 3:] = True
+    return layer, (tgt, mem), dict(tgt_key_padding_mask=tgt_mask, memory_key_padding_mask=mem_mask), dw.normal('gy', (B, A, D), 54).to(DEV)
+
+
+@pytest.mark.parametrize('kind,D,H,F,B,S,A', [('encoder', 768, 8, 2048, 3, 114, 0), ('encoder', 64, 4, 96, 2, 20, 0),
+                                              ('decoder', 768, 8, 2048, 3, 114, 32), ('decoder', 768, 8, 2048, 2, 114, 70), ('decoder', 64, 4, 96, 2, 20, 9)])
+def test_generative_layer_runners_match_the_op_chains(kind, D, H, F, B, S, A):
+    """Eval mode: one node per layer (hip/gen_blocks.py) against the same layer issued op by op (``_forward_ops``): same kernels, same
+    rounding points except where a fused epilogue skips an fp32 round trip -- outputs to 2e-3, every gradient to 1.5e-2."""
+    from vqa_model_builder_amd.modeling.meta_arch import generative_vqa_model as gm
+    layer, inputs, masks, gy = _layer_case(kind, D, H, F, B, S, A)
+    layer.eval()
+    res = {}
+    try:
+        for on in (False, True):
+            gm.LAYER_RUNNERS = on
+            layer.zero_grad(set_to_none=True)
+            xs = [t.clone().requires_grad_(True) for t in inputs]
+            y = layer(*xs, **masks)
+            (y * gy).sum().backward()
+            res[on] = (y.detach(), [x.grad for x in xs], {n: p.grad.clone() for n, p in layer.named_parameters()})
+    finally:
+        gm.LAYER_RUNNERS = True
+    rl = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rl(res[True][0], res[False][0]) <= 2e-3
+    for a, b in zip(res[True][1], res[False][1]):
+        assert rl(a, b) <= 1.5e-2
+    gmax = max(float(g.norm()) for g in res[False][2].values())
+    for n, g0 in res[False][2].items():
+        g1 = res[True][2][n]
+        if float(g0.norm()) < 1e-4 * gmax:                       # e.g. the key bias: softmax is invariant to it
+            assert float(g1.norm()) <= 1e-2 * gmax, n
+            continue
+        assert rl(g1, g0) <= 1.5e-2, (n, rl(g1, g0))
+
+
+@pytest.mark.parametrize('kind,A', [('encoder', 0), ('decoder', 32), ('decoder', 70)])
+def test_generative_layer_runner_training_dropout_is_one_function_forward_and_backward(kind, A):
+    """Train mode (dropout 0.1 on attention probabilities, sub-layer outputs and the FFN activation): backward regenerates the forward's
+    masks -- central differences of <out, g> along the analytic gradient, for every input and two weights."""
+    from vqa_model_builder_amd.hip import blocks as hb
+    hb.disable_indirect_seeds()
+    D, H, F, B, S = 768, 8, 2048, 2, 114
+    layer, inputs, masks, gy = _layer_case(kind, D, H, F, B, S, A)
+    layer.train()
+
+    def f(*xs):
+        torch.manual_seed(777)
+        return layer(*xs, **masks)
+    xs = [t.clone().requires_grad_(True) for t in inputs]
+    y = f(*xs)
+    (y * gy).sum().backward()
+    assert torch.equal(f(*inputs).detach(), y.detach())
+    layer.eval()
+    assert not torch.equal(layer(*inputs, **masks).detach(), y.detach())
+    layer.train()
+    eps = 0.05
+    for i, x in enumerate(inputs):
+        g = xs[i].grad
+        d = g / g.norm() * x.norm()
+        plus = [t if j != i else t + eps * d for j, t in enumerate(inputs)]
+        minus = [t if j != i else t - eps * d for j, t in enumerate(inputs)]
+        num = float(((f(*plus) - f(*minus)) * gy).sum().double()) / (2 * eps)
+        ana = float((g * d).sum().double())
+        assert abs(num - ana) <= 0.05 * abs(ana), (kind, i, num, ana)
+    names = ['linear2.weight', 'self_attn.in_proj_weight'] + (['multihead_attn.in_proj_weight'] if kind == 'decoder' else [])
+    for pname in names:
+        p = dict(layer.named_parameters())[pname]
+        dp = p.grad / p.grad.norm() * p.detach().norm()
+        ana = float((p.grad * dp).sum().double())
+        ew = 0.01
+        with torch.no_grad():
+            p.add_(ew * dp)
+        yp = f(*inputs).detach()
+        with torch.no_grad():
+            p.sub_(2 * ew * dp)
+        ym = f(*inputs).detach()
+        with torch.no_grad():
+            p.add_(ew * dp)
+        num = float(((yp - ym) * gy).sum().double()) / (2 * ew)
+        assert abs(num - ana) <= 0.05 * abs(ana), (kind, pname, num, ana)

@@ -143,6 +143,35 @@ __global__ void act_drop_fwd_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// GatedLinearExpert (reference expert_types.py:501-504): y[t, j] = drop(h[t, j] * sigmoid(h[t, H + j])) over h [T, 2H] fp32
+__global__ void glu_fwd_kernel(const float* __restrict__ h, float* __restrict__ y, int T, int H, float p, float inv_keep, uint64_t seed, uint32_t stream) {
+    if (p > 0.f) seed = resolve_seed(seed);
+    const size_t n = (size_t)T * H, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t t = i / H, j = i % H;
+        const float a = h[t * 2 * H + j], g = h[t * 2 * H + H + j];
+        float v = a / (1.f + __expf(-g));
+        if (p > 0.f) v *= dropout_scale(seed, stream, i, p, inv_keep);
+        y[i] = v;
+    }
+}
+
+// dh[t, j] = dy * keep * sigmoid(g);  dh[t, H + j] = dy * keep * a * sigmoid(g) * (1 - sigmoid(g))
+__global__ void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h, float* __restrict__ dh, int T, int H, float p, float inv_keep,
+                               uint64_t seed, uint32_t stream) {
+    if (p > 0.f) seed = resolve_seed(seed);
+    const size_t n = (size_t)T * H, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t t = i / H, j = i % H;
+        const float a = h[t * 2 * H + j], g = h[t * 2 * H + H + j];
+        const float sg = 1.f / (1.f + __expf(-g));
+        float d = dy[i];
+        if (p > 0.f) d *= dropout_scale(seed, stream, i, p, inv_keep);
+        dh[t * 2 * H + j] = d * sg;
+        dh[t * 2 * H + H + j] = d * a * sg * (1.f - sg);
+    }
+}
+
 constexpr int MAX_E = 16;
 struct PtrsC { const float* p[MAX_E]; };
 struct PtrsM { float* p[MAX_E]; };
@@ -252,6 +281,18 @@ int vqa_act_drop_fwd(const float* x, float* y, void* y_bf16, void* pre_bf16, siz
     if (n == 0) return VQA_OK;
     hipLaunchKernelGGL(act_drop_fwd_kernel, dim3(grid_of(n, 256, 2048)), dim3(256), 0, (hipStream_t)s, x, y, (h16_t*)y_bf16, (h16_t*)pre_bf16, n, act, p,
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
+    return (int)hipGetLastError();
+}
+
+int vqa_glu_fwd(const float* h, float* y, int T, int H, float p, uint64_t seed, uint32_t stream, vqa_stream_t s) {
+    if (!h || !y || T <= 0 || H <= 0 || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_of((size_t)T * H, 256, 2048)), dim3(256), 0, (hipStream_t)s, h, y, T, H, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
+    return (int)hipGetLastError();
+}
+
+int vqa_glu_bwd(const float* dy, const float* h, float* dh, int T, int H, float p, uint64_t seed, uint32_t stream, vqa_stream_t s) {
+    if (!dy || !h || !dh || T <= 0 || H <= 0 || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_of((size_t)T * H, 256, 2048)), dim3(256), 0, (hipStream_t)s, dy, h, dh, T, H, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
     return (int)hipGetLastError();
 }
 

@@ -266,6 +266,18 @@ def rows_mask_cast(dy, M, N, *, pre=None, act=ACT_NONE, drop: Drop = NO_DROP, co
     return out
 
 
+def glu_fwd(h, T, H, drop: Drop = NO_DROP):
+    y = torch.empty((T, H), dtype=F32, device=h.device)
+    _chk(L().vqa_glu_fwd(_p(h), _p(y), T, H, drop.p, drop.seed, drop.stream, _stream()), 'vqa_glu_fwd')
+    return y
+
+
+def glu_bwd(dy, h, T, H, drop: Drop = NO_DROP):
+    dh = torch.empty((T, 2 * H), dtype=F32, device=h.device)
+    _chk(L().vqa_glu_bwd(_p(dy), _p(h), _p(dh), T, H, drop.p, drop.seed, drop.stream, _stream()), 'vqa_glu_bwd')
+    return dh
+
+
 def head_keep_fwd(v, T, R, H, Dh, drop: Drop = NO_DROP):
     out = torch.empty((T * R, H * Dh), dtype=HALF(), device=v.device)
     _chk(L().vqa_head_keep_fwd(_p(v), _p(out), T, R, H, Dh, drop.p, drop.seed, drop.stream, _stream()), 'vqa_head_keep_fwd')

@@ -95,6 +95,8 @@ SIGNATURES = {
     'vqa_moe_dense_combine_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp]),
     'vqa_moe_dense_combine_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_act_drop_fwd': (i32, [vp, vp, vp, vp, sz, i32, f32, u64, u32, vp]),
+    'vqa_glu_fwd': (i32, [vp, vp, i32, i32, f32, u64, u32, vp]),
+    'vqa_glu_bwd': (i32, [vp, vp, vp, i32, i32, f32, u64, u32, vp]),
     'vqa_rows_mask_cast': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, f32, u64, u32, vp]),
     'vqa_head_keep_fwd': (i32, [vp, vp, i32, i32, i32, i32, f32, u64, u32, vp]),
     'vqa_head_keep_bwd': (i32, [vp, vp, i32, i32, i32, i32, f32, u64, u32, vp]),

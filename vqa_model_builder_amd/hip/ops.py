@@ -316,6 +316,33 @@ def activation(x, act, dropout_p=0.0, training=False):
 
 # ---- cross entropy + argmax ------------------------------------------------------------------------------------------------
 
+class _GluFn(torch.autograd.Function):
+    """h [.., 2H] -> drop(h[.., :H] * sigmoid(h[.., H:]))  (reference expert_types.py:501-504)."""
+
+    @staticmethod
+    def forward(ctx, h, p, seed, stream):
+        H = h.shape[-1] // 2
+        h2 = h.reshape(-1, 2 * H).contiguous().float()
+        drop = Drop(p, seed, stream) if p > 0 else NO_DROP
+        y = K.glu_fwd(h2, h2.shape[0], H, drop)
+        ctx.save_for_backward(h2)
+        ctx.meta = (drop, H, h.shape)
+        return y.view(h.shape[:-1] + (H,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h2,) = ctx.saved_tensors
+        drop, H, shape = ctx.meta
+        dh = K.glu_bwd(dy.reshape(-1, H).contiguous().float(), h2, h2.shape[0], H, drop)
+        return dh.view(shape), None, None, None
+
+
+def glu(h, dropout_p=0.0, training=False):
+    _need_cuda(h, 'glu')
+    p = dropout_p if training else 0.0
+    return _GluFn.apply(h, p, new_seed() if p > 0 else 0, 31)
+
+
 class _CEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, label_smoothing):

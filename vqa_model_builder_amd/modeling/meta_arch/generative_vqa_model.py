@@ -1,5 +1,5 @@
 """Generative Vietnamese VQA model on the MI355X HIP path (reference ``src/modeling/meta_arch/generative_vqa_model.py``;
-SURVEY section 8f rank 3 -- STARTED this round: correct, not yet tuned).
+SURVEY section 8f rank 3 -- started in round 2: correct against reference-run fixtures, first tuning pass done).
 
 Same class names, constructor signatures, attribute names and ``state_dict`` keys as the reference: ``GenerativeVQAConfig``
 (:28-105), ``GenerativeVQAOutput`` (:108-116), ``VisualEncoder`` (:119-151), ``QuestionEncoder`` (:154-190), ``CrossModalFusion``
@@ -8,12 +8,12 @@ padding mask, optional MoE, LayerNorm), ``TransformerDecoder`` (:342-451: tied t
 ``nn.TransformerDecoderLayer`` x 6 with causal + padding masks over the fused memory, LayerNorm, tied 64 000-way output projection),
 ``GenerativeVQAModel`` (:479-703: teacher-forced forward with label-smoothed cross entropy, ``generate``).
 
-What runs where: the two encoders are the block runners of the classification path (hip/blocks.py); fusion and decoder layers are
-chains of the per-op HIP autograd nodes (hip/ops.py: Linear with fused bias / GELU / dropout epilogues, LayerNorm, MHA with
-key-padding and -- new -- causal masking, label-smoothed CE); the 64 000 x 768 output projection is one MFMA GEMM over all B x A
-rows (201 GFLOP at B = 32, A = 64: the first GEMM of this code base large enough to run near the matrix cores' rate).  Not built:
-``moe_type='sparse'`` (``SparseMOELayer``), ``moe_position`` 'decoder' / 'both' (the reference never constructs a decoder MoE
-either: ``CrossModalFusion`` is its only MoE site), beam search (the reference's ``generate`` ignores ``num_beams`` too).
+What runs where: the two encoders are the block runners of the classification path (hip/blocks.py); every fusion-encoder and decoder
+layer is one hand-scheduled autograd node (hip/gen_blocks.py; the op-by-op chains of hip/ops.py stay as ``_forward_ops``, the form the
+runners are tested against); embedding, final LayerNorms and the label-smoothed CE are per-op nodes; the 64 000 x 768 output projection
+is one MFMA GEMM over all B x A rows (201 GFLOP at B = 32, A = 64: the first GEMM of this code base large enough to run near the matrix cores' rate).  ``moe_type`` 'standard' / 'vqa' / 'sparse' all build (the reference's own 'sparse' call site raises a TypeError: SURVEY F11).  Not
+built: ``moe_position`` 'decoder' / 'both' (the reference never constructs a decoder MoE either: ``CrossModalFusion`` is its only MoE
+site), beam search (the reference's ``generate`` ignores ``num_beams`` too).
 """
 
 import math
@@ -25,8 +25,10 @@ import torch.nn as nn
 
 from ...hip import kernels as K
 from ...hip import ops
+from ...hip.gen_blocks import PreLNDecoderLayerRunner, PreLNEncoderLayerRunner
 from ...hip.kernels import ACT_GELU, Drop
-from .backbones import ClipVisionBackbone, RobertaBackbone, _require_cuda
+from ...hip.kernels import skip_weight_grads as K_skip
+from .backbones import ClipVisionBackbone, RobertaBackbone, _BlockFn, _Weights, _flatten_param_keys, _require_cuda, _split_grads
 from .vqa_model import _KNOWN_TEXT, _KNOWN_VISION, _MHAParams, _try_load_pretrained
 
 
@@ -161,6 +163,30 @@ class QuestionEncoder(nn.Module):
         return h, attention_mask
 
 
+# True: every fusion-encoder / decoder layer is ONE autograd node (hip/gen_blocks.py).  False: the op-by-op chains (_forward_ops) the
+# runners are tested against.
+LAYER_RUNNERS = True
+
+
+def _bind_layer(layer, cross):
+    """Key -> parameter map + bf16 weight shadows of one Transformer layer (torch's parameter names stay the state_dict's)."""
+    W = _Weights()
+    P, S = W.params, W.shadows
+    pairs = [('sa_in', layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias),
+             ('sa_out', layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)]
+    if cross:
+        pairs += [('ca_in', layer.multihead_attn.in_proj_weight, layer.multihead_attn.in_proj_bias),
+                  ('ca_out', layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias)]
+    pairs += [('l1', layer.linear1.weight, layer.linear1.bias), ('l2', layer.linear2.weight, layer.linear2.bias)]
+    for key, w, b in pairs:
+        P[key + '_w'], P[key + '_b'] = w, b
+        S.add(key + '_w', w, tuple(w.shape))
+    norms = [layer.norm1, layer.norm2] + ([layer.norm3] if cross else [])
+    for i, n in enumerate(norms, 1):
+        P[f'n{i}.w'], P[f'n{i}.b'] = n.weight, n.bias
+    return W
+
+
 class _EncoderLayer(nn.Module):
     """Parameter layout + HIP forward of ``nn.TransformerEncoderLayer(activation='gelu', batch_first=True, norm_first=True)``."""
 
@@ -173,8 +199,30 @@ class _EncoderLayer(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
         self.dropout1, self.dropout2 = nn.Dropout(dropout), nn.Dropout(dropout)
         self._p = dropout
+        self._W = _bind_layer(self, cross=False)
+        self._flat = _flatten_param_keys(self._W.params)
+        self._runner = PreLNEncoderLayerRunner(self._W, d_model, nhead, dim_feedforward, dropout, self.norm1.eps)
+        self._mask = None
+
+    def _hip_forward(self, src):
+        self._W.shadows.refresh(src.device)
+        return self._runner.forward(src, self._mask, self.training)
+
+    def _hip_backward(self, saved, dout, needs):
+        with K_skip(not any(p.requires_grad for _, p in self._flat)):
+            G, dx = self._runner.backward(saved, dout)
+        return [dx], _split_grads(self._flat, G)
 
     def forward(self, src, src_key_padding_mask=None):
+        if LAYER_RUNNERS and src.is_cuda and src.dim() == 3:
+            self._mask = src_key_padding_mask
+            try:
+                return _BlockFn.apply(self, 1, src, *[p for _, p in self._flat])
+            finally:
+                self._mask = None
+        return self._forward_ops(src, src_key_padding_mask)
+
+    def _forward_ops(self, src, src_key_padding_mask=None):
         p, tr = self._p, self.training
         h = ops.layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         a, _ = self.self_attn(h, h, h, key_padding_mask=src_key_padding_mask)
@@ -212,7 +260,12 @@ class CrossModalFusion(nn.Module):
                                          num_specialized_experts=config.num_specialized_experts, top_k=config.num_experts_per_token,
                                          dropout=config.fusion_dropout, vietnamese_optimized=config.vietnamese_optimized)
         elif self.moe_type == 'sparse':
-            raise NotImplementedError("GenerativeVQAConfig(moe_type='sparse'): SparseMOELayer is not built on the HIP path")
+            # the reference's call here is ``SparseMOELayer(config=moe_config)`` (:262), which its own constructor rejects with a TypeError
+            # (SURVEY F11); built instead from the fields that MOEConfig was filled with
+            from ..moe import SparseMOELayer
+            self.moe_layer = SparseMOELayer(input_dim=config.fusion_dim, hidden_dim=config.decoder_ff_dim, output_dim=config.fusion_dim,
+                                            num_experts=config.num_experts, top_k=config.num_experts_per_token,
+                                            capacity_factor=config.expert_capacity_factor, dropout=config.fusion_dropout, use_aux_loss=True)
         else:
             rc = RouterConfig(router_type='topk', num_experts=config.num_experts, top_k=config.num_experts_per_token,
                               capacity_factor=config.expert_capacity_factor, load_balance_weight=config.moe_loss_weight, use_aux_loss=True)
@@ -271,8 +324,30 @@ class _DecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
         self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
         self._p = dropout
+        self._W = _bind_layer(self, cross=True)
+        self._flat = _flatten_param_keys(self._W.params)
+        self._runner = PreLNDecoderLayerRunner(self._W, d_model, nhead, dim_feedforward, dropout, self.norm1.eps)
+        self._masks = (None, None)
+
+    def _hip_forward(self, tgt, memory):
+        self._W.shadows.refresh(tgt.device)
+        return self._runner.forward(tgt, memory, self._masks[0], self._masks[1], self.training)
+
+    def _hip_backward(self, saved, dout, needs):
+        with K_skip(not any(p.requires_grad for _, p in self._flat)):
+            G, dx, dmem = self._runner.backward(saved, dout, need_dmem=needs[1])
+        return [dx, dmem], _split_grads(self._flat, G)
 
     def forward(self, tgt, memory, tgt_key_padding_mask=None, memory_key_padding_mask=None):
+        if LAYER_RUNNERS and tgt.is_cuda and tgt.dim() == 3:
+            self._masks = (tgt_key_padding_mask, memory_key_padding_mask)
+            try:
+                return _BlockFn.apply(self, 2, tgt, memory, *[p for _, p in self._flat])
+            finally:
+                self._masks = (None, None)
+        return self._forward_ops(tgt, memory, tgt_key_padding_mask, memory_key_padding_mask)
+
+    def _forward_ops(self, tgt, memory, tgt_key_padding_mask=None, memory_key_padding_mask=None):
         p, tr = self._p, self.training
         sa = self.self_attn
         h = ops.layer_norm(tgt, self.norm1.weight, self.norm1.bias, self.norm1.eps)

@@ -269,7 +269,7 @@ class MultimodalExpert(BaseExpert):
 
 
 class GatedLinearExpert(BaseExpert):
-    """Reference expert_types.py:448-515 (only reachable through create_expert('glu'); not on the VQA path)."""
+    """Reference expert_types.py:448-515 (reachable through create_expert('glu') / MOEConfig.expert_types)."""
     token_local = True
 
     def __init__(self, input_dim=768, hidden_dim=3072, output_dim=768, expert_id=None, dropout=0.1):
@@ -279,7 +279,10 @@ class GatedLinearExpert(BaseExpert):
         self.layer_norm = nn.LayerNorm(output_dim)
 
     def forward(self, x, mask=None, **kwargs):
-        raise NotImplementedError('GatedLinearExpert has no HIP kernel yet (not constructed by VietnameseVQAModel)')
+        p, tr = self.dropout_rate, self.training
+        h = ops.glu(ops.linear(x, self.fc1.weight, self.fc1.bias), p, tr)             # value | gate halves, gate, dropout: one launch
+        h = ops.linear(h, self.fc2.weight, self.fc2.bias, drop=_drop(p, tr, 32))
+        return _ln(self.layer_norm, h, x if x.size(-1) == self.output_dim else None)
 
 
 def create_expert(expert_type, input_dim, hidden_dim, output_dim, expert_id=None, **kwargs) -> BaseExpert:

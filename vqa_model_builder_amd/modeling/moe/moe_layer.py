@@ -272,15 +272,136 @@ class VQAMOELayer(MOELayer):
 
 
 class SparseMOELayer(nn.Module):
-    """Reference moe_layer.py:199-358 (capacity-constrained dispatch; used only by the generative model, whose
-    call site is itself broken -- SURVEY F11).  Declared for import compatibility."""
+    """Reference moe_layer.py:199-358: NoisyTopKRouter + token dispatch with a per-expert capacity
+    ``int(capacity_factor * tokens * top_k / num_experts)``: an expert over its capacity keeps the tokens with the largest routing
+    weight (``torch.topk`` on the weights, :321-327), the rest contribute nothing (and their routing weight gets no gradient).
+    Each expert sees its tokens as ONE sequence ``[1, C, D]`` (:334) -- irrelevant for token-local experts (the default
+    'feedforward'), reproduced for attention-bearing expert types.  (The generative model's own construction of this class passes
+    ``config=`` and raises ``TypeError`` in the reference: SURVEY F11 -- same here.)"""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('SparseMOELayer belongs to the generative path (SURVEY section 8f rank 3), not built this round')
+    def __init__(self, input_dim: int = 768, hidden_dim: int = 3072, output_dim: int = 768, num_experts: int = 8, top_k: int = 2,
+                 capacity_factor: float = 1.25, dropout: float = 0.1, use_aux_loss: bool = True, expert_type: str = 'feedforward'):
+        super().__init__()
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.num_experts, self.top_k, self.capacity_factor = num_experts, top_k, capacity_factor
+        self.router = NoisyTopKRouter(input_dim=input_dim, num_experts=num_experts, top_k=top_k, use_aux_loss=use_aux_loss)
+        self.experts = nn.ModuleList([create_expert(expert_type=expert_type, input_dim=input_dim, hidden_dim=hidden_dim, output_dim=output_dim,
+                                                    expert_id=i, dropout=dropout) for i in range(num_experts)])
+        self.output_norm = nn.LayerNorm(output_dim)
+        self.aux_outputs: Dict[str, Any] = {}
+
+    def _compute_capacity(self, num_tokens: int) -> int:
+        return int(self.capacity_factor * num_tokens * self.top_k / self.num_experts)
+
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError('SparseMOELayer: HIP path needs GPU tensors; no CPU fallback on the product path')
+        B, S, D = x.shape
+        T, E = B * S, self.num_experts
+        capacity = self._compute_capacity(T)
+        routing_weights, expert_indices, aux_outputs = self.router(x)
+        self.aux_outputs = aux_outputs
+        Kk = expert_indices.shape[-1]
+        w2 = routing_weights.reshape(T, Kk).contiguous().float()
+        i2 = expert_indices.reshape(T, Kk).contiguous().long()
+        dev = x.device
+        w_all = torch.empty((E, T), dtype=torch.float32, device=dev)
+        lists = torch.empty((E, T), dtype=torch.int32, device=dev)
+        counts_dev = torch.empty((E,), dtype=torch.int32, device=dev)
+        K._chk(K.L().vqa_moe_expert_tokens(w2.detach().data_ptr(), i2.data_ptr(), T, Kk, E, w_all.data_ptr(), lists.data_ptr(),
+                                           counts_dev.data_ptr(), K._stream()), 'vqa_moe_expert_tokens')
+        counts = counts_dev.tolist()              # one host sync per layer (the reference: `.any()` per expert + `len(token_indices)`)
+        x2 = x.reshape(T, D)
+        for e in range(E):                        # capacity cut first: the token lists are saved by the autograd nodes below
+            n = counts[e]
+            if n > capacity:                      # keep the `capacity` largest routing weights, in topk's order (:321-327)
+                cand = lists[e, :n].long()
+                top = torch.topk(w_all[e].index_select(0, cand), capacity).indices
+                lists[e, :capacity] = cand.index_select(0, top).to(torch.int32)
+                counts[e] = capacity
+        ys = []
+        for e, expert in enumerate(self.experts):
+            n = counts[e]
+            if n == 0:
+                ys.append(None)
+                continue
+            xe = _GatherRowsFn.apply(x2, lists[e], n)
+            if expert.token_local:
+                ys.append(expert(xe.view(n, 1, D), **kwargs).reshape(n, self.output_dim))
+            else:
+                ys.append(expert(xe.view(1, n, D), **kwargs).reshape(n, self.output_dim))
+        out = _CombineFn.apply(w2, i2, w_all, lists, counts, T, self.output_dim, *ys)
+        out = ops.layer_norm(out, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
+        return out.view(B, S, self.output_dim)
+
+    def get_aux_loss(self) -> torch.Tensor:
+        if 'load_balance_loss' in self.aux_outputs:
+            return self.aux_outputs['load_balance_loss']
+        return torch.tensor(0.0)
 
 
 class HierarchicalMOE(nn.Module):
-    """Reference moe_layer.py:361-548 (examples only)."""
+    """Reference moe_layer.py:361-548 (examples): a TopKRouter over expert GROUPS, one TopKRouter per group over its experts, every
+    chosen expert run on ALL tokens and weighted by group weight x expert weight where both routers chose it, then Linear + LayerNorm.
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('HierarchicalMOE is examples-only in the reference and outside the hot path')
+    out[t] = sum_k sum_g [group_k(t) = g] gw_k(t) * sum_j sum_e [expert^g_j(t) = e] ew^g_j(t) * expert_{g,e}(x)[t]
+    The reference evaluates the same sum with one expert call per (k, g, j, e) combination (:470-507); here each expert that any
+    token selects is called ONCE and its weights are summed first -- identical in eval mode (in train mode the reference draws
+    fresh dropout masks per repeated call).  The load-balance term adds a group's router loss once per top-k slot that reaches the
+    group (:480-484), as there.  Routers, experts, the output projection and LayerNorm are the HIP modules / ops; the routing masks
+    and the weighted sum are plain torch tensor arithmetic."""
+
+    def __init__(self, input_dim: int = 768, hidden_dim: int = 3072, output_dim: int = 768, num_expert_groups: int = 4,
+                 experts_per_group: int = 4, top_k_groups: int = 2, top_k_experts: int = 1, dropout: float = 0.1, expert_types=None):
+        super().__init__()
+        from .router import TopKRouter
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.num_expert_groups, self.experts_per_group = num_expert_groups, experts_per_group
+        self.top_k_groups, self.top_k_experts = top_k_groups, top_k_experts
+        if expert_types is None:
+            expert_types = ['vision', 'text', 'multimodal', 'feedforward']
+            expert_types = (expert_types * num_expert_groups)[:num_expert_groups]
+        self.group_router = TopKRouter(input_dim=input_dim, num_experts=num_expert_groups, top_k=top_k_groups, use_aux_loss=True)
+        self.expert_routers = nn.ModuleList([TopKRouter(input_dim=input_dim, num_experts=experts_per_group, top_k=top_k_experts, use_aux_loss=True)
+                                             for _ in range(num_expert_groups)])
+        self.expert_groups = nn.ModuleList([
+            nn.ModuleList([create_expert(expert_type=expert_types[g], input_dim=input_dim, hidden_dim=hidden_dim, output_dim=output_dim,
+                                         expert_id=g * experts_per_group + e, dropout=dropout) for e in range(experts_per_group)])
+            for g in range(num_expert_groups)])
+        self.output_proj = nn.Linear(output_dim, output_dim)
+        self.output_norm = nn.LayerNorm(output_dim)
+        self.aux_outputs: Dict[str, Any] = {}
+
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError('HierarchicalMOE: HIP path needs GPU tensors; no CPU fallback on the product path')
+        B, S, _ = x.shape
+        group_weights, group_indices, group_aux = self.group_router(x)
+        zero = torch.zeros((), dtype=torch.float32, device=x.device)
+        total_aux = group_aux.get('load_balance_loss', zero)
+        # [G, B, S]: summed group weight of each token for each group, and how many top-k slots reach the group at all
+        gsel = torch.stack([(group_indices == g) for g in range(self.num_expert_groups)])             # [G, B, S, Kg]
+        gw = (gsel.to(group_weights.dtype) * group_weights.unsqueeze(0)).sum(-1)
+        slots = gsel.flatten(1, 2).any(dim=1).sum(dim=1).tolist()                                     # host sync: the reference's `.any()` per (k, g)
+        out = None
+        for g in range(self.num_expert_groups):
+            if slots[g] == 0:
+                continue
+            ew, ei, e_aux = self.expert_routers[g](x)
+            total_aux = total_aux + slots[g] * e_aux.get('load_balance_loss', zero)
+            esel = torch.stack([(ei == e) for e in range(self.experts_per_group)])                    # [Eg, B, S, Ke]
+            cw = (esel.to(ew.dtype) * ew.unsqueeze(0)).sum(-1) * gw[g].unsqueeze(0)                   # [Eg, B, S]
+            used = esel.flatten(1).any(dim=1).tolist()
+            for e in range(self.experts_per_group):
+                if not used[e]:
+                    continue
+                y = self.expert_groups[g][e](x, mask=mask, **kwargs) * cw[e].unsqueeze(-1)
+                out = y if out is None else out + y
+        if out is None:
+            out = torch.zeros((B, S, self.output_dim), dtype=torch.float32, device=x.device)
+        self.aux_outputs = {'load_balance_loss': total_aux, 'group_probs': group_aux.get('router_probs', None)}
+        out = ops.linear(out, self.output_proj.weight, self.output_proj.bias)
+        return ops.layer_norm(out, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
+
+    def get_aux_loss(self) -> torch.Tensor:
+        return self.aux_outputs.get('load_balance_loss', torch.tensor(0.0))
