@@ -370,6 +370,44 @@ def test_cross_entropy_label_smoothing_matches_torch():
     assert torch.allclose(dl, logits.grad, atol=1e-7, rtol=1e-4)
 
 
+@pytest.mark.parametrize('B,C', [(5, 64000), (3, 3001), (4, 1002)])
+def test_cross_entropy_single_pass_rows(B, C):
+    """The one-pass (online softmax) forward over long rows, 16-byte and scalar load paths (C % 4 != 0), a planted tie for the arg-max
+    (first index wins, as torch) and a row whose maximum sits in the last element."""
+    logits = (rnd((B, C), 11) * 4).to(DEV)
+    logits[0, 17] = logits[0, C - 5] = 30.0                      # tie: torch.argmax returns 17
+    logits[1, C - 1] = 40.0
+    labels = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    ref = torch.nn.functional.cross_entropy(logits, labels, label_smoothing=0.1)
+    loss, pred, lse, _ = K.ce_argmax_fwd(logits, labels, B, C, label_smoothing=0.1)
+    assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref)) + 1e-6
+    assert torch.equal(pred, logits.argmax(-1)) and int(pred[0]) == 17 and int(pred[1]) == C - 1
+    assert torch.allclose(lse, torch.logsumexp(logits, -1), atol=1e-5, rtol=1e-6)
+
+
+def test_linear_cross_entropy_is_linear_then_cross_entropy():
+    """ops.linear_cross_entropy (one node: projection, CE, bf16 logits gradient written once) == ops.linear + ops.cross_entropy_argmax:
+    same logits and loss bit for bit, x / weight gradients to the rounding of the bf16 logits gradient (it is bf16 in both forms)."""
+    from vqa_model_builder_amd.hip import ops
+    M, V, D = 96, 6400, 256
+    x0 = rnd((M, D), 21).to(DEV)
+    w = torch.nn.Parameter((rnd((V, D), 22) * D ** -0.5).to(DEV))
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(4)).to(DEV)
+    labels[3] = -100
+    xa = x0.clone().requires_grad_(True)
+    la, pa = ops.cross_entropy_argmax(ops.linear(xa, w, None), labels, 0.1)
+    la.backward()
+    ga, w.grad = w.grad.clone(), None
+    xb = x0.clone().requires_grad_(True)
+    lb, logits, pb = ops.linear_cross_entropy(xb, w, labels, 0.1)
+    assert not logits.requires_grad
+    lb.backward()
+    assert torch.equal(la.detach(), lb.detach()) and torch.equal(pa, pb)
+    assert torch.equal(logits, ops.linear(x0, w, None).detach())
+    for a, b in ((xb.grad, xa.grad), (w.grad, ga)):
+        assert float((a - b).norm() / b.norm()) < 2e-3
+
+
 def test_expert_row_kernels_against_torch():
     """csrc/expert_ops.hip one by one: mask * act' * cast + column sums, attention over ONE key (keep-scale per (sample, head,
     query), forward broadcast and backward reduction consistent with each other and with the attention kernel's key), row repeat /

@@ -67,8 +67,24 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     __shared__ float sm[4]; __shared__ int si[4]; __shared__ float ss[4]; __shared__ float sx[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x;
     const float* x = logits + (size_t)row * ld;
-    float m = -INFINITY; int mi = 0x7fffffff;
-    for (int c = threadIdx.x; c < C; c += 256) { const float v = x[c]; if (v > m) { m = v; mi = c; } }    // first max per thread
+    // ONE pass over the row (online softmax: running maximum + rescaled sum of exponentials per thread), 16-byte loads where the row
+    // allows: at 64 000 classes the two-pass scalar form read 2 x 262 MB at 1.1 TB/s (231 us for 1024 rows)
+    float m = -INFINITY, sum = 0.f, xs = 0.f; int mi = 0x7fffffff;
+    auto take = [&](float v, int c) {
+        if (v > m) { sum = sum * __expf(m - v) + 1.f; m = v; mi = c; }     // first maximum of this thread (c only grows)
+        else sum += __expf(v - m);
+        xs += v;
+    };
+    if ((C & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)logits) & 15) == 0) {
+        for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[c4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) take(v[j], 4 * c4 + j);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) take(x[c], c);
+    }
+    const float m_own = m;
     // arg-max with lowest-index tie-break (torch.argmax returns the first maximal index): wave, then the four waves
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -82,8 +98,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         const float om = sm[w]; const int oi = si[w];
         if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
     }
-    float sum = 0.f, xs = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) { const float v = x[c]; sum += __expf(v - m); xs += v; }
+    sum = m_own == -INFINITY ? 0.f : sum * __expf(m_own - m);           // rescale this thread's partial to the row maximum
     sum = wave_sum(sum);
     if (smooth > 0.f) xs = wave_sum(xs);
     if (lane == 0) { ss[wave] = sum; sx[wave] = xs; }

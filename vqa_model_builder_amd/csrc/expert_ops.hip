@@ -7,14 +7,15 @@
 namespace {
 
 // out[m,n] = bf16(dy[m,n] * act'(pre[m,n]) * keep(m*N+n));  colsum[n] += sum_m out  (the bias gradient; pre-zeroed slot).
-// Thread = 4 consecutive columns x a chunk of 32 rows.
+// Thread = 4 consecutive columns x a chunk of `rpc` rows (32 for the experts' few rows; 8 when M is in the thousands, so that the grid
+// is thousands of waves instead of a few hundred latency-bound ones: 3648 x 768 took 17.5 us with 32-row chunks).
 __global__ __launch_bounds__(64) void rows_mask_cast_kernel(const float* __restrict__ dy, int ld, const h16_t* __restrict__ pre, int act,
                                                             h16_t* __restrict__ outb, float* __restrict__ colsum, int M, int N, float p, float inv_keep,
-                                                            uint64_t seed, uint32_t stream) {
+                                                            uint64_t seed, uint32_t stream, int rpc) {
     const int c4 = blockIdx.x * 64 + threadIdx.x;
     if (c4 * 4 >= N) return;
     if (p > 0.f) seed = resolve_seed(seed);
-    const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
+    const int m0 = blockIdx.y * rpc, m1 = min(M, m0 + rpc);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int m = m0; m < m1; ++m) {
@@ -230,8 +231,9 @@ int vqa_rows_mask_cast(const float* dy, int ld, const void* pre_bf16, int act, v
                        uint64_t seed, uint32_t stream, vqa_stream_t s) {
     if (!dy || !out_bf16 || M <= 0 || N <= 0 || N % 4 || ld % 4 || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
     if (((uintptr_t)dy & 15) || ((uintptr_t)out_bf16 & 7) || (pre_bf16 && ((uintptr_t)pre_bf16 & 7))) return VQA_ERR_ARG;
-    hipLaunchKernelGGL(rows_mask_cast_kernel, dim3(ceil_div(N / 4, 64), ceil_div(M, 32)), dim3(64), 0, (hipStream_t)s, dy, ld, (const h16_t*)pre_bf16, act,
-                       (h16_t*)out_bf16, colsum, M, N, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream);
+    const int rpc = M > 512 ? 8 : 32;
+    hipLaunchKernelGGL(rows_mask_cast_kernel, dim3(ceil_div(N / 4, 64), ceil_div(M, rpc)), dim3(64), 0, (hipStream_t)s, dy, ld, (const h16_t*)pre_bf16, act,
+                       (h16_t*)out_bf16, colsum, M, N, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream, rpc);
     return (int)hipGetLastError();
 }
 

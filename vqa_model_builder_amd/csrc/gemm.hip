@@ -1102,7 +1102,10 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     if (splits <= 0) {
         splits = 1;
         if (can_split && d->allow_split_k) {
-            while (tiles * splits < 192 && d->K / (splits * 2) >= 4 * BK && splits < 16) splits *= 2;
+            // few tiles: fill the chip; a very long reduction (the 64 000-way head's dX: 192 tiles x 1000 k-steps) is also cut while
+            // every part keeps >= 64 k-steps, up to ~4 workgroups per CU
+            while (((tiles * splits < 192 && d->K / (splits * 2) >= 4 * BK) || (tiles * splits < 1024 && d->K / (splits * 2) >= 64 * BK)) && splits < 16)
+                splits *= 2;
         }
     }
     if (splits > 1 && !can_split) return VQA_ERR_ARG;

@@ -91,14 +91,14 @@ def linear_fwd(x_bf16, w_bf16, bias, M, N, K, *, want_f32=False, want_bf16=False
 
 
 def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, residual=None, act_grad_of=None,
-              act_bwd=ACT_NONE, drop: Drop = NO_DROP, ldw=None, ldy=None, colsum=None):
+              act_bwd=ACT_NONE, drop: Drop = NO_DROP, ldw=None, ldy=None, colsum=None, allow_split_k=False):
     """dx[M,K] = (dy[M,N] W[N,K]) * act'(act_grad_of) * dropmask + residual.  ``colsum`` (pre-zeroed [K] fp32) receives the
     column sums of dx before the residual: the bias gradient of the Linear that produced the activation input."""
     dev = dy_bf16.device
     of = torch.empty((M, K), dtype=F32, device=dev) if want_f32 else None
     ob = torch.empty((M, K), dtype=HALF(), device=dev) if want_bf16 else None
     gemm(dy_bf16, w_bf16, M, K, N, ldy or N, ldw or K, True, False, out_f32=of, out_bf16=ob, residual=residual,
-         act_grad_of=act_grad_of, act_bwd=act_bwd, drop=drop, colsum=colsum)
+         act_grad_of=act_grad_of, act_bwd=act_bwd, drop=drop, colsum=colsum, allow_split_k=allow_split_k)
     return of, ob
 
 

@@ -120,7 +120,7 @@ class _LinearFn(torch.autograd.Function):
             dyb = K.cast_bf16(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dxf, _ = K.linear_dx(dyb, wb, M, Np, Kp, want_f32=True)
+            dxf, _ = K.linear_dx(dyb, wb, M, Np, Kp, want_f32=True, allow_split_k=True)     # a long reduction over few tiles (vocabulary head) is cut
             if Kp != Kd:
                 dxf = dxf[:, :Kd].contiguous()
             dx = dxf.view(xshape) if xdtype == F32 else dxf.view(xshape).to(xdtype)
@@ -376,6 +376,54 @@ def cross_entropy_argmax(logits, labels, label_smoothing: float = 0.0):
     if labels.dtype.is_floating_point or labels.dtype == torch.bool:
         raise RuntimeError(f'cross_entropy_argmax: labels must be an integer tensor of class indices (got {labels.dtype})')
     return _CEFn.apply(logits, labels.long().contiguous(), float(label_smoothing))
+
+
+class _LinearCEFn(torch.autograd.Function):
+    """Bias-free projection + mean cross entropy as ONE node (the generative model's tied 64 000-way head): the logits gradient is
+    written once, in the GEMM operand type, by the CE backward -- as two nodes it crossed HBM as 262 MB of fp32 and again as a cast."""
+
+    @staticmethod
+    def forward(ctx, x, weight, labels, label_smoothing):
+        V, D = weight.shape
+        M = x.shape[0]
+        xb = _as_bf16(x.contiguous())
+        wb = _padded_shadow(weight, V, D)
+        logits, _, _ = K.linear_fwd(xb, wb, None, M, V, D, want_f32=True)
+        loss, pred, lse, nvalid = K.ce_argmax_fwd(logits, labels, M, V, label_smoothing)
+        ctx.save_for_backward(xb, wb, logits, labels, lse, nvalid)
+        ctx.meta = (M, V, D, label_smoothing, x.dtype)
+        ctx.mark_non_differentiable(logits, pred)
+        return loss, logits, pred
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits, _dpred):
+        xb, wb, logits, labels, lse, nvalid = ctx.saved_tensors
+        M, V, D, smooth, xdtype = ctx.meta
+        _, dlb = K.ce_bwd(logits, labels, lse, dloss.contiguous().float(), M, V, nvalid=nvalid, want_f32=False, want_bf16=True, label_smoothing=smooth)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = K.linear_dx(dlb, wb, M, V, D, want_f32=True, allow_split_k=True)
+            if xdtype != F32:
+                dx = dx.to(xdtype)
+        if ctx.needs_input_grad[1]:
+            dw = K.linear_dw(dlb, xb, M, V, D)
+        return dx, dw, None, None
+
+
+def linear_cross_entropy(x, weight, labels, label_smoothing: float = 0.0):
+    """(mean CE loss, logits [M, V] fp32 -- an output, not differentiable --, argmax ids) of ``x @ weight^T`` against ``labels``
+    (``ignore_index=-100`` semantics of cross_entropy_argmax).  V and D multiples of 8; other shapes: linear + cross_entropy_argmax."""
+    _need_cuda(x, 'linear_cross_entropy')
+    V, D = weight.shape
+    if x.dim() != 2 or x.shape[1] != D or labels.dim() != 1 or labels.shape[0] != x.shape[0]:
+        raise ValueError(f'linear_cross_entropy: x [M, {D}] and labels [M] expected (got {tuple(x.shape)}, {tuple(labels.shape)})')
+    if labels.dtype.is_floating_point or labels.dtype == torch.bool:
+        raise RuntimeError(f'linear_cross_entropy: labels must be an integer tensor of class indices (got {labels.dtype})')
+    if V % 8 or D % 8:
+        logits = linear(x, weight, None)
+        loss, pred = cross_entropy_argmax(logits, labels, label_smoothing)
+        return loss, logits, pred
+    return _LinearCEFn.apply(x, weight, labels.long().contiguous(), float(label_smoothing))
 
 
 def argmax(logits):

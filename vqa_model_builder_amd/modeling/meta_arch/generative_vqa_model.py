@@ -166,6 +166,8 @@ class QuestionEncoder(nn.Module):
 # True: every fusion-encoder / decoder layer is ONE autograd node (hip/gen_blocks.py).  False: the op-by-op chains (_forward_ops) the
 # runners are tested against.
 LAYER_RUNNERS = True
+# True: output projection + label-smoothed cross entropy as one node when labels are given (logits stay an output, without a gradient)
+FUSED_HEAD_LOSS = True
 
 
 def _bind_layer(layer, cross):
@@ -408,7 +410,9 @@ class TransformerDecoder(nn.Module):
         if config.tie_word_embeddings:
             self.output_projection.weight = self.embedding.weight
 
-    def forward(self, encoder_hidden_states, decoder_input_ids, encoder_attention_mask=None, decoder_attention_mask=None):
+    def forward(self, encoder_hidden_states, decoder_input_ids, encoder_attention_mask=None, decoder_attention_mask=None, return_hidden=False):
+        """``return_hidden`` (not in the reference signature): the normalised decoder states [B, A, D] in front of the output projection
+        (GenerativeVQAModel fuses that projection with the loss: ops.linear_cross_entropy)."""
         _require_cuda(encoder_hidden_states, 'TransformerDecoder')
         B, A = decoder_input_ids.shape
         V, D = self.embedding.weight.shape
@@ -424,6 +428,8 @@ class TransformerDecoder(nn.Module):
         for layer in self.decoder.layers:
             x = layer(x, encoder_hidden_states, tgt_key_padding_mask=tgt_kpm, memory_key_padding_mask=mem_kpm)
         x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        if return_hidden:
+            return x
         return ops.linear(x, self.output_projection.weight, None)                 # [B, A, V]: one MFMA GEMM over all rows
 
     def _generate_causal_mask(self, seq_len, device):
@@ -463,12 +469,21 @@ class GenerativeVQAModel(nn.Module):
         encoder_attention_mask = torch.cat([torch.ones(B, nv, device=pixel_values.device), attention_mask.float()], dim=1)
         if decoder_input_ids is None:
             decoder_input_ids = torch.full((B, 1), self.config.bos_token_id, dtype=torch.long, device=pixel_values.device)
-        logits = self.decoder(encoder_hidden_states=encoder_hidden_states, decoder_input_ids=decoder_input_ids,
-                              encoder_attention_mask=encoder_attention_mask, decoder_attention_mask=decoder_attention_mask)
         loss = None
+        if labels is not None and FUSED_HEAD_LOSS:
+            hidden = self.decoder(encoder_hidden_states=encoder_hidden_states, decoder_input_ids=decoder_input_ids,
+                                  encoder_attention_mask=encoder_attention_mask, decoder_attention_mask=decoder_attention_mask, return_hidden=True)
+            Bd, A, D = hidden.shape
+            loss, logits, _ = ops.linear_cross_entropy(hidden.reshape(Bd * A, D), self.decoder.output_projection.weight, labels.reshape(-1),
+                                                       label_smoothing=self.config.label_smoothing)
+            logits = logits.view(Bd, A, -1)
+        else:
+            logits = self.decoder(encoder_hidden_states=encoder_hidden_states, decoder_input_ids=decoder_input_ids,
+                                  encoder_attention_mask=encoder_attention_mask, decoder_attention_mask=decoder_attention_mask)
+            if labels is not None:
+                V = self.config.vocab_size
+                loss, _ = ops.cross_entropy_argmax(logits.reshape(-1, V), labels.reshape(-1), label_smoothing=self.config.label_smoothing)
         if labels is not None:
-            V = self.config.vocab_size
-            loss, _ = ops.cross_entropy_argmax(logits.reshape(-1, V), labels.reshape(-1), label_smoothing=self.config.label_smoothing)
             if self.config.use_moe and moe_aux_loss > 0:
                 loss = loss + self.config.moe_loss_weight * moe_aux_loss
         return GenerativeVQAOutput(logits=logits, loss=loss, encoder_hidden_states=encoder_hidden_states)
