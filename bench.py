@@ -269,6 +269,79 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
     return res
 
 
+def run_generative(args, device):
+    """SURVEY section 8f rank 3 (the reference's generative model: ViT-B/32 + PhoBERT -> 2 pre-LN fusion layers over the 114 visual + question
+    tokens -> 6-layer decoder, tied 64 000-way head, label-smoothed CE), batch per GPU as the main workload, answers of 32 tokens,
+    teacher-forced training step captured as one HIP graph.  One GPU; reported as the ``generative_config`` object of the line."""
+    import ctypes as C
+    import gc
+    from vqa_model_builder_amd.graph import GraphedTrainStep
+    from vqa_model_builder_amd.hip import blocks as _blocks, lib
+    from vqa_model_builder_amd.modeling.meta_arch.generative_vqa_model import GenerativeVQAConfig, GenerativeVQAModel
+    from vqa_model_builder_amd.optim import FusedAdamW
+    B, A = args.batch, 32
+    torch.manual_seed(0)
+    cfg = GenerativeVQAConfig(visual_arch=dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, image_size=224, patch_size=32),
+                              text_arch=dict(vocab_size=64001, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                                             max_position_embeddings=258, type_vocab_size=1, pad_token_id=1))
+    model = GenerativeVQAModel(cfg).to(device).train()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+    nd = ('bias', 'LayerNorm.weight', 'layer_norm.weight', 'norm')
+    named = list(model.named_parameters())
+    groups = [{'params': [p for n, p in named if not any(t in n for t in nd)], 'weight_decay': 0.01},
+              {'params': [p for n, p in named if any(t in n for t in nd)], 'weight_decay': 0.0}]
+    opt = FusedAdamW(groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0, loss_scale='dynamic' if args.dtype == 'fp16' else None).attach_shadows(model)
+    g = torch.Generator(device=device).manual_seed(4321)
+    batch = dict(pixel_values=torch.randn((B, 3, 224, 224), generator=g, device=device), input_ids=torch.randint(3, 30000, (B, 64), generator=g, device=device),
+                 attention_mask=torch.ones((B, 64), dtype=torch.int64, device=device),
+                 decoder_input_ids=torch.randint(3, 64000, (B, A), generator=g, device=device),
+                 decoder_attention_mask=torch.ones((B, A), dtype=torch.int64, device=device), labels=torch.randint(3, 64000, (B, A), generator=g, device=device))
+    n_params = sum(p.numel() for p in model.parameters())
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        out = model(**batch)
+        (opt.scale_loss(out.loss) if hasattr(opt, 'scale_loss') else out.loss).backward()
+        opt.step()
+        return out.loss
+    graphed = GraphedTrainStep(model, opt, batch, warmup=3)
+    for _ in range(max(5, args.warmup // 2)):
+        graphed(batch)
+    torch.cuda.synchronize()
+    steps = max(10, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = graphed(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    res = {'name': 'generative_vit_phobert', 'workload': 'GenerativeVQAModel: ViT-B/32 + PhoBERT + 2 fusion layers (114 tokens) + 6-layer decoder + tied 64000-way head',
+           'batch_per_gpu': B, 'answer_tokens': A, 'ms_per_step': round(ms, 3), 'value': round(B / ms * 1e3, 2), 'unit': 'samples/s', 'steps': steps,
+           'launch': 'hip-graph (one graph)', 'final_loss': round(float(loss), 4), 'params': n_params}
+    if not args.no_roofline:
+        model.parallel_towers = False
+        L = lib.load()
+        eager_step()
+        L.vqa_gemm_profile(1, 0)
+        for _ in range(2):
+            eager_step()
+        torch.cuda.synchronize()
+        f, m, n = (C.c_double * 1)(), (C.c_double * 1)(), (C.c_int * 1)()
+        L.vqa_gemm_profile_collect(1, f, m, n)
+        L.vqa_gemm_profile(0, 0)
+        tf = f[0] / m[0] / 1e9 if m[0] > 0 else 0.0
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_v1_kernel / gemm_v1_grouped_kernel (all MFMA GEMM launches of a step)', 'achieved': round(tf, 2),
+                           'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4), 'gemm_gflop_per_step': round(f[0] / 2 / 1e9, 1),
+                           'gemm_ms_per_step': round(m[0] / 2, 3), 'launches_per_step': n[0] // 2, 'traffic': None}
+    graphed = opt = model = None
+    _blocks.disable_indirect_seeds()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -420,6 +493,13 @@ def main():
             args.force_segmented = False
             dp_model = {'error': f'{type(e).__name__}: {e}'}
 
+    gen_res = None
+    if world == 1 and not args.no_second_workload and not args.eager and not args.torch_optimizer:
+        try:
+            gen_res = run_generative(args, device)
+        except Exception as e:                       # noqa: BLE001 -- a report, never a reason to lose the main number
+            gen_res = {'name': 'generative_vit_phobert', 'error': f'{type(e).__name__}: {e}'}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -437,7 +517,7 @@ def main():
                        'step': 'fwd+bwd(train mode, dropout on)+allreduce+clip_grad_norm(1.0)+AdamW', 'parallelism': f'dp{world}',
                        'launch': main_res['launch'], 'final_loss': main_res['final_loss'],
                        **{k: main_res[k] for k in ('loss_scale', 'ranks_seen', 'allreduce_bytes', 'grad_dtype', 'exposed_comm_ms', 'segment_bytes', 'segment_ms', 'segment_gather_bytes_per_rank') if k in main_res}},
-            'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res, 'dp_model': dp_model,
+            'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res, 'dp_model': dp_model, 'generative_config': gen_res,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

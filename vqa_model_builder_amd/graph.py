@@ -65,7 +65,7 @@ class GraphedTrainStep:
         self.static = {k: v.clone() for k, v in batch.items()}
         dev = next(iter(self.static.values())).device
         _blocks.enable_indirect_seeds(dev)
-        if parallel_towers and hasattr(model, 'encode_visual'):
+        if parallel_towers and (hasattr(model, 'encode_visual') or hasattr(model, 'encode_both')):
             model.parallel_towers = True
         for m in model.modules():                      # MoE layers: dispatch without the host read of the routing counts
             if hasattr(m, 'enable_dense_dispatch'):

@@ -459,11 +459,29 @@ class GenerativeVQAModel(nn.Module):
                 if p.dim() > 1:
                     nn.init.xavier_uniform_(p)
 
+    def encode_both(self, pixel_values, input_ids, attention_mask):
+        """The two encoders; with ``parallel_towers`` set (graph.GraphedTrainStep does) the vision tower runs on a side HIP stream -- its
+        backward follows it there -- so the two towers are parallel branches of the captured step (vqa_model.VietnameseVQAModel.encode_both)."""
+        if getattr(self, 'parallel_towers', False) and pixel_values.is_cuda:
+            main = torch.cuda.current_stream()
+            if getattr(self, '_tower_stream', None) is None:
+                self._tower_stream = torch.cuda.Stream()
+            side = self._tower_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                visual_features = self.visual_encoder(pixel_values)
+            question_features, question_mask = self.question_encoder(input_ids, attention_mask)
+            main.wait_stream(side)
+            visual_features.record_stream(main)
+        else:
+            visual_features = self.visual_encoder(pixel_values)
+            question_features, question_mask = self.question_encoder(input_ids, attention_mask)
+        return visual_features, question_features, question_mask
+
     def forward(self, pixel_values, input_ids, attention_mask, decoder_input_ids=None, decoder_attention_mask=None, labels=None,
                 return_dict: bool = True) -> GenerativeVQAOutput:
         _require_cuda(pixel_values, 'GenerativeVQAModel')
-        visual_features = self.visual_encoder(pixel_values)
-        question_features, question_mask = self.question_encoder(input_ids, attention_mask)
+        visual_features, question_features, question_mask = self.encode_both(pixel_values, input_ids, attention_mask)
         encoder_hidden_states, moe_aux_loss = self.fusion(visual_features, question_features, question_mask)
         B, nv = pixel_values.size(0), visual_features.size(1)
         encoder_attention_mask = torch.cat([torch.ones(B, nv, device=pixel_values.device), attention_mask.float()], dim=1)
