@@ -273,7 +273,9 @@ def test_reference_trainer_drives_a_model_with_our_signature():
         "assert 'loss' in m and any(not torch.equal(a, b) for a, b in zip(before, model.parameters())), m\n"
         "apply_training_strategy(model, 'linear_probe'); assert {n.split('.')[0] for n, p in model.named_parameters() if p.requires_grad} == {'answer_head'}\n"
         "print('ok')\n") % REPO
-    r = subprocess.run([sys.executable, '-B', '-c', code], capture_output=True, text=True, cwd='/tmp/golden_cwd', timeout=600)
+    import tempfile
+    with tempfile.TemporaryDirectory() as cwd:       # the reference's trainer writes logs / checkpoints relative to its cwd
+        r = subprocess.run([sys.executable, '-B', '-c', code], capture_output=True, text=True, cwd=cwd, timeout=600)
     if r.returncode != 0 and 'ok' not in r.stdout:
         pytest.skip('reference trainer not constructible here: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200])
 
