@@ -150,7 +150,9 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
     params = [p for p in model.parameters() if p.requires_grad]
     n_params = sum(p.numel() for p in params)
     # the fused optimiser applies 1/world itself (grad_prescale): the all-reduced SUM is never rescaled in memory
-    reducer = GradReducer(params, average=args.torch_optimizer, grad_dtype=args.grad_dtype) if (world > 1 or getattr(args, 'force_segmented', False)) else None
+    dist_on = world > 1 or args.force_dist           # a process group exists (N > 1, or the one-rank RCCL run of --force-dist)
+    reducer = (GradReducer(params, average=args.torch_optimizer, grad_dtype=args.grad_dtype, force_collectives=args.force_dist)
+               if (dist_on or getattr(args, 'force_segmented', False)) else None)
     if world > 1 and not args.torch_optimizer:
         opt.grad_prescale = 1.0 / world
     px, ids, mask, labels = synthetic_batch(args.batch, device, rank)
@@ -182,11 +184,11 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         try:
             graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer, segmented=True if getattr(args, 'force_segmented', False) else None,
                                        moe_branches=1 if args.moe_branches is None else args.moe_branches,
-                                       capture_error_mode='thread_local' if world > 1 else 'global')
+                                       capture_error_mode='thread_local' if dist_on else 'global')
         except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
             ok = 0
             print(f'[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); eager step', file=sys.stderr, flush=True)
-        if world > 1:
+        if dist_on:
             flag = torch.tensor([ok], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
@@ -200,7 +202,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +214,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -224,7 +226,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
     if reducer is not None:
         comm = graphed.comm_stats() if (graphed is not None and hasattr(graphed, 'comm_stats')) else {}
         ranks = torch.ones(1, device=device)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(ranks)
         res.update({'ranks_seen': int(ranks.item()), 'allreduce_bytes': reducer.bytes_per_step(), 'grad_dtype': args.grad_dtype, **comm})
 
@@ -366,6 +368,9 @@ def main():
     ap.add_argument('--group-persistent', type=int, default=None, help='diagnostics: vqa_set_gemm_group_persistent (workgroups of the grouped weight-gradient launches)')
     ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the captured HIP graph of the step')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='diagnostics on a one-GPU box: initialise a ONE-rank RCCL process group and run the N > 1 code path (segmented step, every '
+                         'all-reduce / all-gather really issued) -- exercises RCCL, not its performance')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -377,8 +382,11 @@ def main():
     rehearse = os.environ.get('VQA_BENCH_REHEARSE') == '1'
     if rehearse:
         local_rank = 0
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
         if rehearse:
             dist.init_process_group('gloo')
@@ -413,7 +421,7 @@ def main():
         from vqa_model_builder_amd.modeling.moe import experts as _E
         _E.EXPERT_RUNNERS = bool(args.expert_runners)
     if args.grad_dtype is None:
-        args.grad_dtype = 'bf16' if world > 1 else 'fp32'
+        args.grad_dtype = 'bf16' if (world > 1 or args.force_dist) else 'fp32'
     main_res = run_workload(args.workload, args, device, world, rank, dist, want_roofline=not args.no_roofline)
     moe_res = None
     if not args.no_second_workload and args.workload != 'cfg3_mcan_moe4':
@@ -520,7 +528,7 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu, 'moe_config': moe_res, 'dp_model': dp_model, 'generative_config': gen_res,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

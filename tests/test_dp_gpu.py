@@ -163,3 +163,68 @@ def test_segmented_data_parallel_step_with_moe_dense_dispatch():
             assert abs(a - b) <= 5e-2 * max(1.0, abs(a)), (r, eager[r][0], graph[r][0])
         assert abs(eager[r][1] - graph[r][1]) <= 2e-4 * eager[r][1], (eager[r][1], graph[r][1])
     assert abs(graph[0][1] - graph[1][1]) <= 1e-9 * graph[0][1]
+
+
+def _rccl_worker(rank, world, port, q, wire):
+    """ONE rank over the real RCCL backend ('nccl'): the seven-graph data-parallel step with every all-reduce / all-gather really issued
+    (GradReducer(force_collectives=True)), against the plain one-graph step of the same model on the same batch."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    try:
+        from oracle import det_weights as dw
+        from oracle.gen_golden import TINY
+        from tests.helpers import build_model
+        from vqa_model_builder_amd.dp import GradReducer
+        from vqa_model_builder_amd.graph import GraphedTrainStep
+        from vqa_model_builder_amd.optim import FusedAdamW
+        d = TINY
+        px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=d['vocab'], num_answers=d['num_answers'], seed=50)
+        batch = dict(pixel_values=px.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
+        res = {}
+        for mode in ('plain', 'rccl'):
+            model = build_model({'dims': TINY, 'fusion_type': 'cross_attention', 'num_experts': 0})
+            model.load_state_dict(dw.make_state_dict(dw.shapes_of(model.state_dict()), 5))
+            model = model.to('cuda:0').eval()
+            params = [p for p in model.parameters() if p.requires_grad]
+            opt = FusedAdamW(params, lr=2e-4, weight_decay=0.01, max_grad_norm=1.0).attach_shadows(model)
+            red = None
+            if mode == 'rccl':
+                red = GradReducer(params, bucket_mb=0.5, average=False, grad_dtype=wire, force_collectives=True)
+                assert not red.single
+            gs = GraphedTrainStep(model, opt, batch, reducer=red, warmup=2, capture_error_mode='thread_local')
+            losses = [gs(batch).item() for _ in range(3)]
+            torch.cuda.synchronize()
+            info = dict(segmented=gs.segmented, stats=gs.comm_stats() if red is not None else {}, backend=dist.get_backend())
+            res[mode] = (losses, float(sum(p.detach().double().abs().sum().item() for p in params)), info)
+            del gs, opt, model
+        t = torch.ones(4, device='cuda')
+        dist.all_reduce(t)
+        dist.barrier()
+        q.put((rank, res, t.cpu().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('wire,tol', [('fp32', 1e-5), ('bf16', 2e-3)])
+def test_segmented_step_over_one_rank_rccl(wire, tol):
+    """RCCL itself (torch.distributed backend 'nccl') on the one GPU a box has: communicator set-up, in-place all-reduce of the gradient arenas
+    on RCCL's stream beside the next graph's replay, the bf16 wire copies, the all-gather of the embedding rows.  With one rank every sum is the
+    identity, so the step must reproduce the one-graph step (exactly with fp32 buckets; to bf16 rounding of the gradients with bf16 buckets)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_rccl_worker, args=(0, 1, port, q, wire))]
+    procs[0].start()
+    from tests.helpers import collect_from_workers
+    (_, res, ones), = collect_from_workers(q, procs, 1)
+    procs[0].join(timeout=120)
+    assert procs[0].exitcode == 0
+    assert ones == [1.0] * 4 and res['rccl'][2]['backend'] == 'nccl'
+    assert res['rccl'][2]['segmented'] and set(res['rccl'][2]['stats']['segment_bytes']) == {'H', 'T', 'T2', 'V', 'V2'}
+    for a, b in zip(res['plain'][0], res['rccl'][0]):
+        assert abs(a - b) <= max(tol, 1e-5) * max(1.0, abs(a)), res
+    assert abs(res['plain'][1] - res['rccl'][1]) <= max(tol, 1e-6) * res['plain'][1], res

@@ -38,9 +38,12 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 64.0, process_group=None, average: bool = True,
-                 grad_dtype: str = 'fp32'):
+                 grad_dtype: str = 'fp32', force_collectives: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # ``force_collectives``: issue every collective even in a ONE-rank process group (a one-GPU box is the only hardware the build
+        # sees: this is how the RCCL code path -- communicator, streams, bf16 sums, all-gathers beside graph replays -- runs there)
+        self.single = self.world == 1 and not (force_collectives and dist.is_available() and dist.is_initialized())
         self.average = average
         if grad_dtype not in ('fp32', 'bf16'):
             raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
@@ -77,7 +80,7 @@ class GradReducer:
     # ---- overlap mode (eager step) -----------------------------------------------------------------------------------
     def attach(self):
         """Registers the per-parameter hooks (idempotent).  Use ``finalize()`` instead of ``reduce()`` afterwards."""
-        if self._hooks or self.world == 1:
+        if self._hooks or self.single:
             return self
         for b in self.buckets:
             for p in b.params:
@@ -126,7 +129,7 @@ class GradReducer:
     @torch.no_grad()
     def finalize(self):
         """Call after ``loss.backward()`` in overlap mode."""
-        if self.world == 1:
+        if self.single:
             return
         device = self.buckets[0].params[0].device
         if not self._armed:
@@ -209,7 +212,7 @@ class GradReducer:
     @torch.no_grad()
     def reduce(self):
         """Call after ``loss.backward()``.  Sums (and averages) every gradient across ranks."""
-        if self.world == 1:
+        if self.single:
             return
         device = self.buckets[0].params[0].device
         self._ensure(device)
@@ -327,7 +330,7 @@ class GradReducer:
     def reduce_segment(self, name: str):
         """Launches the (asynchronous) all-reduce of one segment on the communication stream: it is ordered after everything the
         current stream has been given so far (the segment's backward graph) and runs beside whatever is enqueued next."""
-        if self.world == 1:
+        if self.single:
             return
         seg = self._segments[name]
         bufs = seg['stage'] if seg['stage'] is not None else seg['flats']
@@ -371,7 +374,7 @@ class GradReducer:
     @torch.no_grad()
     def reduce_static(self):
         """All segments back to back (no overlap): the round-1 exchange between the backward and the optimiser graph."""
-        if self.world == 1:
+        if self.single:
             return
         for name in self._segments:
             self.pack_segment(name)

@@ -74,7 +74,7 @@ class GraphedTrainStep:
         self._defer_wgrad = defer_wgrad
         can_segment = hasattr(model, 'encode_both') and hasattr(model, 'forward_from_features')
         if segmented is None:
-            segmented = reducer is not None and getattr(reducer, 'world', 1) > 1 and can_segment
+            segmented = reducer is not None and not getattr(reducer, 'single', True) and can_segment
         self.segmented = bool(segmented and can_segment and reducer is not None)
         # every encoder's backward is cut once more (upper / lower half of its layers): the upper half's arena leaves while the
         # lower half computes, and only half of the LAST encoder's arena is left to travel when the step's compute is done
@@ -315,7 +315,7 @@ class GraphedTrainStep:
     def _sync_routed_counts(self):
         """Dense MoE dispatch: an expert is updated when ANY rank routed a token to it (its reduced gradient is the same on every
         rank, so the decision must be too -- the warm-up steps included, they are real training steps)."""
-        if getattr(self.reducer, 'world', 1) <= 1:
+        if getattr(self.reducer, 'single', True):
             return
         for m in self.model.modules():
             a = getattr(m, '_active', None)
