@@ -280,6 +280,51 @@ def test_reference_trainer_drives_a_model_with_our_signature():
         pytest.skip('reference trainer not constructible here: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200])
 
 
+@pytest.mark.skipif(not os.path.isdir('/root/reference/src'), reason='needs the reference tree (build container only)')
+def test_reference_checkpoint_manager_round_trips_the_hip_model_and_fused_adamw():
+    """the REFERENCE's own CheckpointManager (src/pipeline/trainer/checkpoint_manager.py:224-298 save, :403-491 load; imported
+    from /root/reference, build container only) writes and reads the HIP model (parameters + the experts' buffers) and FusedAdamW's state: every
+    tensor returns bit for bit into a model built with other weights, the optimiser's state / hyper-parameters come back, best / latest paths resolve.
+    (Its file carries ``torch.__version__`` as a TorchVersion object, which torch >= 2.6 refuses under the default ``weights_only=True`` for ANY model:
+    the class is allow-listed here, nothing is unpickled unsafely.  The GPU side -- a resumed run continues like the uninterrupted one -- is
+    tests/test_graph_gpu.py::test_checkpoint_resume_continues_the_run.)"""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch; sys.path.insert(0, '/root/reference'); sys.path.insert(0, %r)\n"
+        "from src.pipeline.trainer.checkpoint_manager import CheckpointManager\n"
+        "from tests.helpers import build_model\n"
+        "from tests.conftest import load_golden\n"
+        "from oracle import det_weights as dw\n"
+        "from vqa_model_builder_amd.optim import FusedAdamW\n"
+        "_, meta = load_golden('tiny_mcan_moe4')\n"
+        "def make(seed, lr):\n"
+        "    m = build_model(meta); m.load_state_dict(dw.make_state_dict(dw.shapes_of(m.state_dict()), seed))\n"
+        "    return m, FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=lr, weight_decay=0.01, max_grad_norm=1.0)\n"
+        "model, opt = make(5, 2e-4)\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "for p in opt.param_groups[0]['params']:\n"
+        "    opt.state[p] = {'step': 3, 'exp_avg': torch.randn(p.shape, generator=g), 'exp_avg_sq': torch.rand(p.shape, generator=g)}\n"
+        "cm = CheckpointManager(save_dir='ck', prefix='vqa', max_keep=2, metric_name='accuracy', metric_mode='max')\n"
+        "path = cm.save(model, optimizer=opt, epoch=1, global_step=3, metrics={'accuracy': 0.5})\n"
+        "best = cm.save_best(model, 0.5, optimizer=opt, epoch=1, global_step=3); assert best is not None and cm.get_best_checkpoint_path() is not None\n"
+        "m2, o2 = make(6, 1e-3)\n"
+        "with torch.serialization.safe_globals([torch.torch_version.TorchVersion]):\n"
+        "    info = cm.load(path, m2, optimizer=o2)\n"
+        "a, b = model.state_dict(), m2.state_dict()\n"
+        "assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)\n"
+        "assert any(k.endswith('usage_count') for k in a)\n"
+        "assert o2.param_groups[0]['lr'] == 2e-4 and len(o2.state) == len(opt.state)\n"
+        "for p, q in zip(opt.param_groups[0]['params'], o2.param_groups[0]['params']):\n"
+        "    assert int(o2.state[q]['step']) == 3 and torch.equal(opt.state[p]['exp_avg'], o2.state[q]['exp_avg']) and torch.equal(opt.state[p]['exp_avg_sq'], o2.state[q]['exp_avg_sq'])\n"
+        "assert cm.get_latest_checkpoint_path() is not None\n"
+        "print('ok')\n") % REPO
+    with tempfile.TemporaryDirectory() as cwd:
+        r = subprocess.run([sys.executable, '-B', '-c', code], capture_output=True, text=True, cwd=cwd, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
 def test_pipeline_config_surface():
     from vqa_model_builder_amd.core import ModelPipelineConfig, TrainingPipelineConfig, VQAPipelineConfig, build_model_config
     mc = ModelPipelineConfig(fusion_type='mcan', use_moe=True, moe_num_experts=4)

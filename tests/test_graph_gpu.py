@@ -284,3 +284,44 @@ def test_replays_follow_the_batches_they_are_given():
             assert abs(x - y) <= 1e-2 * max(1.0, abs(x)), (ref, got)
     finally:
         blocks.disable_indirect_seeds()
+
+
+@pytest.mark.parametrize('resume_as', ['eager', 'graph'])
+def test_checkpoint_resume_continues_the_run(tmp_path, resume_as):
+    """the layout the reference's CheckpointManager writes and reads (checkpoint_manager.py:152-199 ``_create_checkpoint_dict``:
+    ``model_state_dict`` / ``optimizer_state_dict`` / counters through ``torch.save``; ``load`` :450-459: ``torch.load`` -> ``model.load_state_dict``
+    -> ``optimizer.load_state_dict``) round-trips the HIP model and FusedAdamW: a run resumed from the file -- into a model built with OTHER weights,
+    so the 16-bit weight shadows must follow the loaded parameters -- continues like the uninterrupted one, eagerly and as a replayed graph, and the
+    optimiser's step counts (bias correction) carry on from the checkpoint."""
+    from vqa_model_builder_amd.graph import GraphedTrainStep
+    from vqa_model_builder_amd.hip import blocks
+    n0, n1 = 3, 4
+    model, opt, batch = _setup(train=False)
+    first = _eager(model, opt, batch, n0)
+    path = tmp_path / 'checkpoint_epoch_1.pt'
+    torch.save({'epoch': 1, 'global_step': n0, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': opt.state_dict(),
+                'metrics': {'loss': first[-1]}, 'best_metric': first[-1]}, path)
+    cont = _eager(model, opt, batch, n1)
+    assert first[0] - cont[-1] > 0.03, (first, cont)
+    try:
+        model2, opt2, _ = _setup(train=False, seed=6)
+        before = _eager(model2, opt2, batch, 1)                     # the other weights are in use (shadows materialised) before the load
+        assert abs(before[0] - first[0]) > 1e-3
+        ck = torch.load(path, map_location='cuda:0')                # weights_only=True (torch >= 2.6 default): tensors and numbers only
+        model2.load_state_dict(ck['model_state_dict'], strict=True)
+        opt2.load_state_dict(ck['optimizer_state_dict'])
+        assert {int(s['step']) for s in opt2.state.values()} == {n0}
+        if resume_as == 'eager':
+            got = _eager(model2, opt2, batch, n1)
+        else:
+            gs = GraphedTrainStep(model2, opt2, batch, warmup=1)   # the warm-up step is a real training step (its loss is not returned)
+            got = [float('nan')] + [gs(batch).item() for _ in range(n1 - 1)]
+        for a, b in zip(cont, got):
+            if b == b:
+                assert abs(a - b) <= (1e-5 if resume_as == 'eager' else 1e-2) * max(1.0, abs(a)), (cont, got)
+        sd = opt2.state_dict()
+        assert {int(s['step']) for s in sd['state'].values()} == {n0 + n1}
+        sig = lambda m: float(sum(p.detach().double().abs().sum().item() for p in m.parameters()))
+        assert abs(sig(model) - sig(model2)) <= (1e-7 if resume_as == 'eager' else 1e-4) * sig(model)
+    finally:
+        blocks.disable_indirect_seeds()
