@@ -496,6 +496,22 @@ __device__ __forceinline__ h16x8 load_frag1(const char* lds, int o0, int o1, int
     u.s.a = lo; u.s.b = hi;
     return u.v;
 }
+// gemm_v1_body (the waves that read fragments are the waves that keep DMAs in flight): the k-contiguous read goes through inline asm as
+// well.  Behind the plain C++ load the compiler placed an s_waitcnt vmcnt(0) in the MIDDLE of the fragment reads of some instances (64x64
+// tiles on the 3-stage ring, both operands k-contiguous = every Linear forward with N < 1536: ISA of round 2, found when the fc2-forward shape
+// 2048 x 768 x 3072 measured 33 us whatever the ring depth while its transposed-B twin took 20 us) -- the same may-alias-the-DMA reasoning as
+// for the transposing read, applied per LDS offset: the ring was drained in two of three k-steps.
+template <int ROWS, bool KC>
+__device__ __forceinline__ h16x8 load_frag1_asm(const char* lds, int o0, int o1, int s) {
+#ifdef VQA_KC_PLAIN_READS                  // A/B builds only (scratch/ab_build.sh): the round-1 form
+    return load_frag1<ROWS, KC>(lds, o0, o1, s);
+#endif
+    if (!KC) return load_frag1<ROWS, KC>(lds, o0, o1, s);
+    const unsigned base = (unsigned)(uintptr_t)lds;                 // low 32 bits of a flat LDS address = LDS byte offset
+    h16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(base + (s ? o1 : o0)));
+    return v;
+}
 template <bool ANY_RC, int NA, int NB>
 __device__ __forceinline__ void frag_fence(h16x8 (&fa)[NA], h16x8 (&fb)[NB]) {
     if (!ANY_RC) return;
@@ -582,10 +598,14 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
                 for (int ks = 0; ks < BKT / 32; ++ks) {
                     h16x8 fa[TM], fb[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = load_frag1<BM, A_KC>(la, ao0[i], ao1[i], ks);
+                    for (int i = 0; i < TM; ++i) fa[i] = load_frag1_asm<BM, A_KC>(la, ao0[i], ao1[i], ks);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = load_frag1<BN, B_KC>(lb, bo0[j], bo1[j], ks);
+                    for (int j = 0; j < TN; ++j) fb[j] = load_frag1_asm<BN, B_KC>(lb, bo0[j], bo1[j], ks);
+#ifdef VQA_KC_PLAIN_READS
                     frag_fence<!A_KC || !B_KC>(fa, fb);
+#else
+                    frag_fence<true>(fa, fb);
+#endif
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -909,6 +929,11 @@ int launch_v1s(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st
 // version measured equal or slower on every shape of the path -- profiles/r01/gemm_tiles.log -- and are no longer built.)
 template <int BM, int BN, int WM_, int WN_>
 int launch_v1(const GemmArgs& p, int a_kc, int b_kc, int splits, int stages, hipStream_t st) {
+    // deeper rings for the long-k shapes (K = 3072 with N = 768: A alone is 12.6 MB, nothing of the operands stays in an XCD's 4-MiB L2, every
+    // k-step's DMA pays the memory-side latency -- the loop is bound by bytes in flight, not by L2 -> LDS bandwidth)
+    if constexpr (BM == 64 && BN == 64) {
+        if (stages >= 4) return launch_v1s<BM, BN, WM_, WN_, 64, 4>(p, a_kc, b_kc, splits, st);
+    }
     if constexpr ((BM + BN) * 64 * 2 * 3 <= 160 * 1024 && BM * BN <= 128 * 64) {
         if (stages >= 3) return launch_v1s<BM, BN, WM_, WN_, 64, 3>(p, a_kc, b_kc, splits, st);
     }
