@@ -576,6 +576,7 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifndef VQA_GEMM_SWP        // default.  -DVQA_GEMM_SWP (scratch/ab_build.sh) builds the software-pipelined loop below instead
     for (int kt0 = 0; kt0 < nk; kt0 += STAGES1) {
 #pragma unroll
         for (int s = 0; s < STAGES1; ++s) {                  // compile-time stage index: LDS addresses fold to immediates
@@ -615,6 +616,77 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
             }
         }
     }
+#else
+    // Software-pipelined k loop (BKT = 64 = two 32-deep substeps per tile): a wave's fragment reads of substep 1 are issued BEFORE the
+    // MFMAs of substep 0, and the reads of the NEXT tile's substep 0 before the MFMAs of substep 1; tile kt+1 is awaited (counted vmcnt +
+    // s_barrier) between the two MFMA batches of tile kt, when every wave has finished READING tile kt, and its stage refilled there.
+    // MEASURED, NOT ADOPTED (round 2, same-box A/B, gpurun_out s2_ab_swp: bit-exact on every layout test): single launches 0 - 3 %
+    // faster (three waves per SIMD already hide the LDS round trip), the grouped 128 x 128 weight-gradient launch SLOWER (293 -> 451 us:
+    // the second fragment set takes the kernel from 136 to 324 registers, i.e. from two workgroups per CU to one), the step 7.25 ->
+    // 7.72 ms.  And at one workgroup per CU the pipelined loop equals the serial one (23.4 vs 23.6 % of peak): the LDS round trip is
+    // not what bounds that loop -- the waves' own DMA issue (~60 cycles per 1-KiB global_load_lds, 8 per wave and k-step on a 128 x 128
+    // tile = as long as the k-step's 32 MFMAs) is, which is the L1 -> LDS path's 64 B/clk seen from the issuing wave.
+    static_assert(BKT == 64, "two substeps per ring stage");
+    auto wait_tile = [&](int t) {                            // tile t landed for this wave; younger tiles may stay in flight
+        const int rem = min(nk - 1 - t, STAGES1 - 2);
+        if (STAGES1 >= 6 && rem >= 4) wait_vmcnt<4 * GL>();
+        else if (STAGES1 >= 5 && rem >= 3) wait_vmcnt<3 * GL>();
+        else if (STAGES1 >= 4 && rem >= 2) wait_vmcnt<2 * GL>();
+        else if (STAGES1 >= 3 && rem >= 1) wait_vmcnt<GL>();
+        else wait_vmcnt<0>();
+    };
+    h16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    if (nk > 0) {
+        wait_tile(0);
+        __builtin_amdgcn_s_barrier();
+        if (STAGES1 - 1 < nk) issue(STAGES1 - 1, STAGES1 - 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa0[i] = load_frag1_asm<BM, A_KC>(smem, ao0[i], ao1[i], 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb0[j] = load_frag1_asm<BN, B_KC>(smem + A_BYTES, bo0[j], bo1[j], 0);
+    }
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES1) {
+#pragma unroll
+        for (int s = 0; s < STAGES1; ++s) {                  // compile-time stage index: LDS addresses fold to immediates
+            const int kt = kt0 + s;
+            if (kt < nk) {
+                const char* la = smem + s * STAGE_BYTES;
+                const char* lb = la + A_BYTES;
+                frag_fence<true>(fa0, fb0);                  // substep 0 of tile kt is in registers (issued one MFMA batch ago)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa1[i] = load_frag1_asm<BM, A_KC>(la, ao0[i], ao1[i], 1);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb1[j] = load_frag1_asm<BN, B_KC>(lb, bo0[j], bo1[j], 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = VQA_MFMA16(fb0[j], fa0[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                frag_fence<true>(fa1, fb1);                  // every read of tile kt by this wave is complete
+                if (kt + 1 < nk) {
+                    wait_tile(kt + 1);
+                    __builtin_amdgcn_s_barrier();            // tile kt+1 landed for every wave; every wave is done reading stage s
+#ifdef VQA_GEMM_TRACE
+                    if (kt + 1 < 24) VQA_T(2 + kt + 1);
+#endif
+                    if (kt + STAGES1 < nk) issue(kt + STAGES1, s);
+                    const char* na = smem + ((s + 1) % STAGES1) * STAGE_BYTES;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa0[i] = load_frag1_asm<BM, A_KC>(na, ao0[i], ao1[i], 0);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb0[j] = load_frag1_asm<BN, B_KC>(na + A_BYTES, bo0[j], bo1[j], 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = VQA_MFMA16(fb1[j], fa1[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#endif
     static_assert(NW * EpiScratch<TN>::BYTES <= STAGES1 * STAGE_BYTES, "epilogue scratch does not fit the ring");
     __syncthreads();                                         // every wave is done with the ring: it becomes epilogue scratch
     VQA_T(26);
@@ -1169,10 +1241,10 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     }
 }
 int g_group_persistent = 0; // > 0: grouped launches run persistent on at most this many workgroups (vqa_set_gemm_group_persistent)
-template <int BM, int BN, int ST, bool AK, bool BKC>
+template <int BM, int BN, int ST, bool AK, bool BKC, int WM_ = 2, int WN_ = 2>
 static int launch_grouped(const GroupArgs& g, hipStream_t st) {
     constexpr int LDS = ST * (BM + BN) * 64 * 2;
-    auto kern = gemm_v1_grouped_kernel<BM, BN, 2, 2, 64, ST, AK, BKC>;
+    auto kern = gemm_v1_grouped_kernel<BM, BN, WM_, WN_, 64, ST, AK, BKC>;
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1183,7 +1255,7 @@ static int launch_grouped(const GroupArgs& g, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) flop += 2.0 * g.it[i].M * g.it[i].N * g.it[i].K;
     int grid = g.tile_end[g.n - 1];
     if (g_group_persistent > 0 && grid > g_group_persistent) grid = g_group_persistent / 8 * 8;      // a multiple of 8: the XCD remap stays a bijection
-    vqa_launch(kern, dim3(grid), dim3(256), LDS, st, g, flop);
+    vqa_launch(kern, dim3(grid), dim3(WM_ * WN_ * 64), LDS, st, g, flop);
     return (int)hipGetLastError();
 }
 
@@ -1209,7 +1281,10 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     // FLOP does: 128x128 once there are >= 3 rounds of them over the 256 CUs, else the 64x64 tile of the single launches.
     int tile = g_group_tile;
     if (tile == 0) tile = t64 / 4 >= 3 * 256 ? 3 : 1;
-    const int bm = tile == 1 ? 64 : 128, bn = tile == 3 ? 128 : 64;
+    // lab tiles (vqa_set_gemm_group_tile; scratch/group_dw_bench.py, none beats 128x128 / 2 stages at two workgroups per CU: 32 % of peak):
+    // 4: 256x128 8 waves 2 stages (29 %); 5: 256x128 8 waves 3 stages (32 %); 7: 128x128 3 stages, one workgroup per CU (22 %)
+    if (tile == 6 || tile > 7) return VQA_ERR_ARG;
+    const int bm = tile == 1 ? 64 : (tile == 4 || tile == 5) ? 256 : 128, bn = (tile == 1 || tile == 2) ? 64 : 128;
     GroupArgs g{};
     g.n = n;
     long tiles = 0;
@@ -1223,7 +1298,9 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     // ring depth as for single launches: the third stage pays when k is long and the grid is under two workgroups per CU
     const bool deep = tile == 1 && kmin >= 2048 && tiles < 512;
     hipStream_t st = (hipStream_t)stream_;
-#define VQA_G(AK, BKC) (tile == 3 ? launch_grouped<128, 128, 2, AK, BKC>(g, st) : tile == 2 ? launch_grouped<128, 64, 2, AK, BKC>(g, st) \
+#define VQA_G(AK, BKC) (tile == 4 ? launch_grouped<256, 128, 2, AK, BKC, 4, 2>(g, st) : tile == 5 ? launch_grouped<256, 128, 3, AK, BKC, 4, 2>(g, st) \
+                        : tile == 7 ? launch_grouped<128, 128, 3, AK, BKC>(g, st) \
+                        : tile == 3 ? launch_grouped<128, 128, 2, AK, BKC>(g, st) : tile == 2 ? launch_grouped<128, 64, 2, AK, BKC>(g, st) \
                         : deep ? launch_grouped<64, 64, 3, AK, BKC>(g, st) : launch_grouped<64, 64, 2, AK, BKC>(g, st))
     if (!a_kc && !b_kc) return VQA_G(false, false);
     if (a_kc && b_kc) return VQA_G(true, true);
