@@ -63,6 +63,7 @@ struct GemmArgs {
     int tiles_n; unsigned tiles_n_magic;    // tile columns of the launch's tile shape and ceil(2^32 / tiles_n) (0 when tiles_n == 1): the
                                             // tile-id -> (row, column) split costs one multiply instead of a ~40-instruction integer division
     float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
+    int epi_dma;                            // epilogue operand staged through LDS by DMA (ring kernels): 0 none, 1 act_grad_of, 2 residual (host: alignment)
 #ifdef VQA_GEMM_TRACE
     unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
 #endif
@@ -137,6 +138,8 @@ struct Stage {
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
 
 // fragment of 16 rows (r0..r0+15) x 32 k (substep s) for lane: rows on lane&15, k = 8*(lane>>4)+j
 template <int ROWS, bool KC, bool USE_TR>
@@ -204,8 +207,18 @@ template <int TM, int TN> constexpr int epi_group(int avail, int nw) {
     return g;
 }
 
-template <int TM, int TN, int G>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch) {
+// ODMA (ring kernels): the wave tile of the ONE global epilogue operand of the launch -- the saved pre-activation (act_grad_of) or the fp32
+// residual; the host sets GemmArgs::epi_dma only when exactly one of them is present -- is fetched into a per-wave LDS strip ``oper``
+// (epi_oper_bytes<TM, TN>()) by LDS-DMA before the C tile is turned, and the rolled loop reads it from there through inline asm.  Read from
+// global inside the loop, every iteration sat out its own dependent L2 / HBM round trip AND, because loads and stores share vmcnt, the
+// completion of the previous iteration's global stores: 8 such iterations per wave on a 128x64 tile were the +6 us the GELU' epilogue cost
+// the fc2 input-gradient GEMM (profiles/r01/gemm_epilogue_costs.log).  Prefetching through registers needs the loop unrolled, and unrolled
+// code is cold-instruction-cache time; with the operand in LDS the loop holds no global load at all, so nothing in it waits on vmcnt.
+// (The two forms are separate instantiations: with both in one body the compiler waits vmcnt(0) before the asm LDS read anyway -- it
+// overwrites the register the other path's global load may still be filling.)
+template <int TM, int TN> constexpr int epi_oper_bytes() { return (TM * 16 * TN * 16 * 4 + 1023) / 1024 * 1024; }     // sized for fp32
+template <int TM, int TN, int G, bool ODMA = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch, char* oper = nullptr) {
     const bool splitk = gridDim.z > 1;
     // dropout key: resolved here, at its only use (an INDIRECT seed costs one scalar load whose latency hides behind the stores);
     // resolving it at kernel entry by patching a copy of the argument struct put the struct in scratch memory and opened every
@@ -240,46 +253,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    const int okind = ODMA ? p.epi_dma : 0;
+    const int oper_rb = TN * 16 * (okind == 1 ? 2 : 4);                 // bytes per row of the wave tile in the staged operand
+    if (ODMA) {
+        const int esz = okind == 1 ? 2 : 4, lpr = oper_rb >> 4, rpi = 64 / lpr;       // 16-B lanes per row, rows per 1-KiB DMA instruction
+        const char* gsrc = okind == 1 ? reinterpret_cast<const char*>(p.act_grad_of) : reinterpret_cast<const char*>(p.residual);
+        const size_t pitch = (size_t)(okind == 1 ? p.ld_ag : p.ld_res) * esz;
+        const int nmax = p.N - 16 / esz;                                 // last whole 16-B chunk of a row (host: N % 8 == 0 for 16-bit operands)
+#pragma unroll 1
+        for (int i = 0; i * rpi < TM * 16; ++i) {
+            const int row = min(i * rpi + lane / lpr, TM * 16 - 1);
+            const int m = min(m_base + row, p.M - 1), nn = max(0, min(n_base + (lane % lpr) * (16 / esz), nmax));     // clamped rows / chunks are never used
+            unsigned long long addr = reinterpret_cast<unsigned long long>(gsrc + (size_t)m * pitch + (size_t)nn * esz);
+            asm volatile("" : "+v"(addr));
+            __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(oper + i * 1024), 16, 0, 0);
+        }
+    }
+    // The groups of G strips (as many as the ring holds beside the operand strip) are walked by a ROLLED loop as well: only the
+    // accumulator -> scratch writes are specialised per group (registers cannot be indexed at run time), the body exists once.
+#pragma unroll 1
+    for (int g = 0; g < TM / G; ++g) {
+        const int i0 = g * G;
 #pragma unroll
-    for (int i0 = 0; i0 < TM; i0 += G) {
-        // G strips of 16 rows go through the scratch together (as many as the ring holds)
+        for (int gg = 0; gg < TM / G; ++gg) {
+            if (gg == g) {
 #pragma unroll
-        for (int i = 0; i < G; ++i)
+                for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * EpiScratch<TN>::BYTES + wr_off + j * 64) = acc[i0 + i][j] * p.alpha;
+                    for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * EpiScratch<TN>::BYTES + wr_off + j * 64) = acc[gg * G + i][j] * p.alpha;
+            }
+        }
+        if (ODMA && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the staged operand landed (under the turn's LDS writes)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ROLLED (the body carries every fused option; unrolled TM x 16/RPI times it was ~100 KB of once-executed code that ran at
         // instruction-fetch speed -- and even a 4x unrolled chunk measured 6 % slower over the step than this form: at one cold
-        // launch per kernel, code size is time).  The global LOADS of the body (saved activation for act', fp32 residual) are
-        // software-pipelined two rows ahead through three rotating register sets: rolled naively, every iteration sat out its own
-        // dependent L2 / HBM load (~600 cycles x 8 - 16 iterations = the in-kernel timeline's 6300-cycle epilogue).
+        // launch per kernel, code size is time).
         constexpr int NQ = G * 16 / RPI;
-        h16x4 pv0, pv1, pv2; f32x4 rv0, rv1, rv2;
-        auto prefetch = [&](int q, h16x4& pv, f32x4& rv) {
-            const int m = m_base + 16 * i0 + q * RPI + rd_row;
-            if (q < NQ && m < p.M && nok) {
-                if (p.act_grad_of) pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
-                if (p.residual) rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n);
-            }
-        };
-#ifndef VQA_EPI_PREFETCH
-#define VQA_EPI_PREFETCH 0      // 1 = two-rows-ahead software-pipelined loads.  A/B inside one gpurun call (scratch/ab_build.sh, bench cfg2, two
-                                // alternating runs each): 7.735 / 7.749 ms with, 7.654 / 7.647 ms without -- the extra registers and moves cost more
-                                // than the hidden latency returns; kept as a build option
-#endif
-        const bool has_loads = p.act_grad_of || p.residual;
-        if (VQA_EPI_PREFETCH && has_loads) { prefetch(0, pv0, rv0); prefetch(1, pv1, rv1); }
 #pragma unroll 1
         for (int q = 0; q < NQ; ++q) {
-            if (has_loads) prefetch(VQA_EPI_PREFETCH ? q + 2 : q, VQA_EPI_PREFETCH ? pv2 : pv0, VQA_EPI_PREFETCH ? rv2 : rv0);
             const int row = q * RPI + rd_row;            // 0 .. 16 G - 1 (scratch rows are contiguous across the G strips)
-            const int m = m_base + 16 * i0 + row;
+            const int trow = 16 * i0 + row, m = m_base + trow;
             if (m < p.M && nok) {
+                h16x4 pv; f32x4 rv;
+                if (ODMA) {
+                    // inline asm: behind a plain LDS load the compiler waits for every outstanding global STORE of the loop (vmcnt
+                    // counts them too) on the grounds that the load may alias an LDS-DMA
+                    const unsigned oaddr = (unsigned)(uintptr_t)oper + trow * oper_rb;
+                    if (okind == 1) asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pv) : "v"(oaddr + col * 2));
+                    else asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rv) : "v"(oaddr + col * 4));
+                } else {
+                    if (p.act_grad_of) pv = *reinterpret_cast<const h16x4*>(p.act_grad_of + (size_t)m * p.ld_ag + n);
+                    if (p.residual) rv = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ld_res + n);
+                }
                 f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * PITCH + col * 4) + bv;
-                if (p.act_grad_of) {
+                if (ODMA ? okind == 1 : p.act_grad_of != nullptr) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv0[r], p.act_bwd_kind);
+                    for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], p.act_bwd_kind);
                 }
                 if (p.pre_bf16) {
                     h16x4 o;
@@ -293,7 +323,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 }
                 if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
                 cs += v;                                  // column sums of the stored values BEFORE the residual (bias gradient)
-                if (p.residual) v += rv0;
+                if (ODMA ? okind == 2 : p.residual != nullptr) v += rv;
                 if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
                 if (p.c_bf16) {
                     h16x4 o;
@@ -302,7 +332,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                     *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
                 }
             }
-            if (VQA_EPI_PREFETCH) { pv0 = pv1; rv0 = rv1; pv1 = pv2; rv1 = rv2; }
         }
         __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
     }
@@ -409,8 +438,6 @@ __device__ __forceinline__ int kc1_key(int row) { return ((row >> 3) & 1) << 1; 
 template <int BKT> __device__ __forceinline__ int kcT_key(int row) { return BKT == 64 ? ((row >> 1) & 7) : kc1_key(row); }
 template <int BKT> __device__ __forceinline__ int kcT_off(int row, int chunk) { return row * (BKT * 2) + ((chunk ^ kcT_key<BKT>(row)) << 4); }
 
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 
 // Per-lane DMA descriptor of one 1-KiB wave-instruction of an operand tile: everything that does not depend on the
 // k-step is computed ONCE (row clamp, swizzled chunk, zero-page redirection); the k loop only adds `step` to `ptr`.
@@ -690,8 +717,16 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     static_assert(NW * EpiScratch<TN>::BYTES <= STAGES1 * STAGE_BYTES, "epilogue scratch does not fit the ring");
     __syncthreads();                                         // every wave is done with the ring: it becomes epilogue scratch
     VQA_T(26);
+    // ring layout in the epilogue: [NW x EG scratch strips][NW x operand strip] when both fit, else scratch only (operands read from global)
+    constexpr int OPER = epi_oper_bytes<TM, TN>();
+    constexpr bool OPER_OK = NW * (EpiScratch<TN>::BYTES + OPER) <= STAGES1 * STAGE_BYTES;
     constexpr int EG = epi_group<TM, TN>(STAGES1 * STAGE_BYTES, NW);
-    gemm_epilogue<TM, TN, EG>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
+    constexpr int EGD = OPER_OK ? epi_group<TM, TN>(STAGES1 * STAGE_BYTES - NW * OPER, NW) : 1;
+    if (OPER_OK && p.epi_dma)
+        gemm_epilogue<TM, TN, EGD, true>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EGD * EpiScratch<TN>::BYTES,
+                                         smem + NW * EGD * EpiScratch<TN>::BYTES + wave * OPER);
+    else
+        gemm_epilogue<TM, TN, EG>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
 #ifdef VQA_GEMM_TRACE
     VQA_T(27);
     wait_vmcnt<0>();
@@ -704,8 +739,15 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
 #endif
 }
 
+// waves per SIMD the ring's LDS footprint allows (workgroups per CU x waves per workgroup / 4 SIMDs, at most 4): given to the register
+// allocator as the occupancy to keep -- the 128x64 forward kernel sat 4 registers over the 168 that three workgroups per CU need
+constexpr int ring_waves_per_simd(int lds_bytes, int nw) {
+    int wg = 160 * 1024 / lds_bytes, w = wg * nw / 4;
+    return w < 1 ? 1 : w > 4 ? 4 : w;
+}
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WM_ * WN_ * 64) __attribute__((amdgpu_waves_per_eu(ring_waves_per_simd(STAGES1 * (BM + BN) * BKT * 2, WM_ * WN_))))
+void gemm_v1_kernel(const GemmArgs p) {
     const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
     // PERSISTENT when the host capped the grid (vqa_set_gemm_grid_cap): workgroup b walks tiles b, b + G, b + 2G ...  A capped
     // grid leaves LDS / wave slots on every CU for the kernels of an independent launch chain (the other encoder's
@@ -1158,6 +1200,13 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
     p.colsum = d->colsum;
+    // the launch's ONE global epilogue operand (saved pre-activation or residual, not both) is staged through LDS by DMA
+    // (16-byte chunks: row starts and the row end must be 16-byte aligned); see gemm_epilogue
+    p.epi_dma = 0;
+#ifndef VQA_EPI_NO_DMA
+    if (d->act_grad_of && !d->residual && d->ld_ag % 8 == 0 && d->N % 8 == 0 && !((uintptr_t)d->act_grad_of & 15)) p.epi_dma = 1;
+    else if (d->residual && !d->act_grad_of && !((uintptr_t)d->residual & 15)) p.epi_dma = 2;          // ld_res % 4 and N % 4 are enforced above
+#endif
 
     // tile choice: fill >= ~256 workgroups where the shape allows it
     int cfg;   // 0: 128x128, 1: 64x64, 2: 32x128 (skinny M), 3: 128x32 (skinny N), 4: 128x64, 5: 64x128, 6: 256x128 (8 waves), 7: 32x32, 8: 32x64
