@@ -101,7 +101,7 @@ def _train_worker(rank, world, port, q, mode):
                               grad_dtype='bf16' if 'bf16' in mode else 'fp32')
             opt.grad_prescale = 1.0 / world
             gs = GraphedTrainStep(model, opt, batch, reducer=red, warmup=warm, capture_error_mode='thread_local',
-                                  segmented=False if 'flat' in mode else None)
+                                  segmented=False if 'flat' in mode else None, dp_split='towers' if 'towers' in mode else 'depth')
             losses = [float('nan')] * warm + [gs(batch).item() for _ in range(n - warm)]
             torch.cuda.synchronize()
             info = dict(segmented=gs.segmented, stats=gs.comm_stats(), describe=gs.describe(),
@@ -130,17 +130,19 @@ def _run_two(mode):
     return res
 
 
-@pytest.mark.parametrize('mode,tol', [('graph', 1e-4), ('graph_flat', 1e-4), ('graph_bf16', 2e-3)])
+@pytest.mark.parametrize('mode,tol', [('graph', 1e-4), ('graph_towers', 1e-4), ('graph_flat', 1e-4), ('graph_bf16', 2e-3)])
 def test_graphed_data_parallel_step_matches_eager_data_parallel_step(mode, tol):
-    """'graph': the seven-graph step (encoders fwd | fusion+head fwd+bwd | text bwd upper half | lower half | vision bwd upper | lower | optimiser)
-    with every block's gradient arena all-reduced beside the next block's graph; 'graph_flat': round 1's forward+backward graph -> exchange -> optimiser
+    """'graph': the depth-segmented step (encoders fwd | fusion+head fwd+bwd | B1 .. Bn: the text AND vision layers of one depth range as parallel branches
+    of one graph | optimiser) with every segment's gradient runs all-reduced beside the next segment's graph; 'graph_towers': one tower at a time (text bwd upper half |
+    lower half | vision bwd upper | lower); 'graph_flat': round 1's forward+backward graph -> exchange -> optimiser
     graph; 'graph_bf16': bfloat16 gradient buckets on the wire.  All against the eager step with hook-overlapped buckets."""
     eager, graph = _run_two('eager'), _run_two(mode)
     assert graph[0][2]['segmented'] == (mode != 'graph_flat'), graph[0][2]
     if mode != 'graph_flat':
         st = graph[0][2]['stats']
-        assert set(st['segment_bytes']) == {'H', 'T', 'T2', 'V', 'V2'} and st['exposed_comm_ms'] >= 0.0, st      # each encoder backward in two graphs
-        assert set(st['segment_ms']) == {'F', 'H', 'T', 'T2', 'V', 'V2'}, st
+        segs = {'H', 'T', 'T2', 'V', 'V2'} if mode == 'graph_towers' else {'H', 'B1', 'B2'}      # the tiny towers have two layers each: two depth segments
+        assert set(st['segment_bytes']) == segs and st['exposed_comm_ms'] >= 0.0, st
+        assert set(st['segment_ms']) == segs | {'F'}, st
         assert graph[0][2]['sparse'] == 1                  # the word-embedding gradient travelled as gathered (ids, rows)
         assert min(st['segment_bytes'].values()) > 0, st
     for r in (0, 1):
@@ -224,7 +226,7 @@ def test_segmented_step_over_one_rank_rccl(wire, tol):
     procs[0].join(timeout=120)
     assert procs[0].exitcode == 0
     assert ones == [1.0] * 4 and res['rccl'][2]['backend'] == 'nccl'
-    assert res['rccl'][2]['segmented'] and set(res['rccl'][2]['stats']['segment_bytes']) == {'H', 'T', 'T2', 'V', 'V2'}
+    assert res['rccl'][2]['segmented'] and set(res['rccl'][2]['stats']['segment_bytes']) == {'H', 'B1', 'B2'}
     for a, b in zip(res['plain'][0], res['rccl'][0]):
         assert abs(a - b) <= max(tol, 1e-5) * max(1.0, abs(a)), res
     assert abs(res['plain'][1] - res['rccl'][1]) <= max(tol, 1e-6) * res['plain'][1], res

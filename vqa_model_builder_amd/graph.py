@@ -18,21 +18,25 @@ expert no token chose is skipped by the optimiser through a device-side routed-t
 ONE GPU: one graph for the whole step (two parallel encoder branches, all weight-gradient GEMMs grouped at the end).
 
 DATA PARALLEL (a ``dp.GradReducer`` is given): collectives stay outside captures, so the step is cut where the gradient
-exchange can start -- the autograd graph is severed at the encoder outputs and the step becomes SEVEN graphs
+exchange can start -- the autograd graph is severed at the encoder outputs and the step becomes a chain of graphs
 
-    F       both encoders forward (parallel branches)
-    H       fusion + MoE + answer head forward AND backward  -> gradients of the head / fusion / MoE and of the encoder outputs
-    T, T2   text-encoder backward: upper half of the layers | lower half + embeddings   (resumable runner backward: blocks.py)
-    V, V2   vision-encoder backward, likewise
-    O       clip + AdamW (+ loss-scale update)
+    F          both encoders forward (parallel branches)
+    H          fusion + MoE + answer head forward AND backward  -> gradients of the head / fusion / MoE and of the encoder outputs
+    B1 .. B4   the encoders' backward cut BY DEPTH (``dp_split='depth'``, default): segment j holds the text AND the vision layers of
+               one quarter of the depth as parallel branches of one graph (resumable runner backward: blocks.py ``backward_steps``);
+               the last one also the embeddings.  (``dp_split='towers'``, the first form of round 2: T, T2 = text backward upper / lower
+               half, then V, V2 = vision backward -- one tower at a time: 8.8 - 9.0 ms per step against 8.4 - 8.5 ms by depth, same box.)
+    O          clip + AdamW (+ loss-scale update)
 
-and the host replays  F, H, [all-reduce H], T, [all-reduce T], T2, [...], V, [...], V2, [all-reduce V2], wait, O:  every
-``all_reduce`` is asynchronous on RCCL's own stream, IN PLACE on the contiguous runs of the segment's gradients inside the block's
-arena, ordered after the graph that produced them and running beside the next graph, so only the LAST half-block's exchange (180 MB
-fp32 / 90 MB with bf16 buckets) is exposed -- round 1 exposed all 0.98 GB between one backward graph and the optimiser graph.
-``comm_stats()`` reports the measured exposed time and the GPU time of every graph; tests/test_dp_gpu.py checks the captured step
-against the eager data-parallel step.  Forks inside a capture are ONE level deep (a fork nested in a forked branch faults in this
-runtime: profiles/r02/nested_fork_capture.md).
+and the host replays  F, H, [all-reduce H], B1, [all-reduce B1], ..., B4, [all-reduce B4], wait, O:  every ``all_reduce`` is
+asynchronous on RCCL's own stream, IN PLACE on the contiguous runs of the segment's gradients inside the blocks' arenas, ordered after
+the graph that produced them and running beside the next graph, so only the LAST segment's exchange (a quarter of the encoders: 97 MB
+fp32 / 48 MB with bf16 buckets, plus the gathered embedding rows) is exposed -- round 1 exposed all 0.98 GB between one backward graph
+and the optimiser graph.  ``comm_stats()`` reports the measured exposed time and the GPU time of every graph; tests/test_dp_gpu.py
+checks the captured step against the eager data-parallel step (both splits, fp32 and bf16 buckets, MoE, and over a one-rank RCCL
+group).  Forks inside a capture are ONE level deep (a fork nested in a forked branch faults in this runtime:
+profiles/r02/nested_fork_capture.md): in B2 .. B4 the vision tower's resume runs on the tower side stream, forked from and joined to
+the capture stream directly.
 """
 
 from typing import Callable, Dict, Optional
@@ -46,7 +50,7 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
-                 moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True):
+                 moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True, dp_split: str = 'depth'):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -57,6 +61,9 @@ class GraphedTrainStep:
         B=32: 13.7 -> 10.6 ms/step).  ``defer_wgrad``: weight-gradient GEMMs are issued grouped at the end of their graph.
         ``sparse_embeddings`` (segmented step): the word-embedding gradient is exchanged as gathered (ids, rows) (dp.prepare_static).
         ``split_encoders`` (segmented step): each encoder's backward as two graphs (upper / lower half of its layers).
+        ``dp_split`` (segmented step): 'depth' (default) cuts BOTH encoders' backward by depth into up to four graphs B1 .. B4, each
+        holding the text and the vision layers of that depth as parallel branches (the two towers keep filling each other's gaps, as in
+        the one-graph step); 'towers' is the first form of this round: text backward (T, T2) then vision backward (V, V2), one tower at a time.
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
         ``forward_from_features``): the multi-graph data-parallel step described in the module docstring."""
@@ -78,8 +85,17 @@ class GraphedTrainStep:
         self.segmented = bool(segmented and can_segment and reducer is not None)
         # every encoder's backward is cut once more (upper / lower half of its layers): the upper half's arena leaves while the
         # lower half computes, and only half of the LAST encoder's arena is left to travel when the step's compute is done
-        self._order, self._splits = ('H', 'T', 'V'), {}
-        if self.segmented and split_encoders:
+        self._order, self._splits, self._depth = ('H', 'T', 'V'), {}, None
+        tb = getattr(getattr(model, 'text_encoder', None), 'encoder', None)
+        vb = getattr(getattr(model, 'visual_encoder', None), 'backbone', None)
+        if (self.segmented and split_encoders and dp_split == 'depth' and all(b is not None and hasattr(b, 'resume_backward') for b in (tb, vb))
+                and min(tb.config.num_hidden_layers, vb.config.num_hidden_layers) >= 2 and getattr(model, 'parallel_towers', False)):
+            # depth-wise segments: segment j of n holds layers [cut[j], cut[j-1]) of each tower (descending), the last one the embeddings too
+            n = min(4, tb.config.num_hidden_layers, vb.config.num_hidden_layers)
+            self._depth = {'n': n, 'blocks': {'T': tb, 'V': vb},
+                           'cuts': {k: [b.config.num_hidden_layers - (b.config.num_hidden_layers * j) // n for j in range(1, n)] for k, b in (('T', tb), ('V', vb))}}
+            self._order = ('H',) + tuple(f'B{j + 1}' for j in range(n))
+        elif self.segmented and split_encoders:
             order = ['H']
             for seg, blk in (('T', getattr(getattr(model, 'text_encoder', None), 'encoder', None)),
                              ('V', getattr(getattr(model, 'visual_encoder', None), 'backbone', None))):
@@ -98,7 +114,7 @@ class GraphedTrainStep:
                 if self.segmented:
                     self._segment_F()
                     for name in self._order:
-                        getattr(self, '_segment_' + name)()
+                        self._segment_fn(name)()
                 else:
                     self._fwd_bwd()
                 if reducer is not None:
@@ -135,7 +151,7 @@ class GraphedTrainStep:
             pool = self.g_main.pool()
             order = self._order
             for name in order:
-                fn = getattr(self, '_segment_' + name)
+                fn = self._segment_fn(name)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, **kw):
                     fn()
@@ -232,6 +248,42 @@ class GraphedTrainStep:
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
 
+    def _segment_fn(self, name):
+        if self._depth is not None and name.startswith('B'):
+            j = int(name[1:]) - 1
+            return (lambda: self._depth_first()) if j == 0 else (lambda: self._depth_resume(last=(j == self._depth['n'] - 1)))
+        return getattr(self, '_segment_' + name)
+
+    def _depth_first(self):
+        """B1: both encoders' autograd nodes in ONE backward call -- the vision node runs on the side stream its forward ran on (a parallel
+        branch of the capture), each node stops after its top segment of layers (split_backward_after) and hands out the gradient views."""
+        d = self._depth
+        for k, blk in d['blocks'].items():
+            blk.split_backward_after = tuple(d['cuts'][k])
+        try:
+            self._encoder_backward((0, 1, 2, 3))
+        finally:
+            for blk in d['blocks'].values():
+                blk.split_backward_after = None
+
+    def _depth_resume(self, last):
+        """B2 ..: the next segment of layers of both towers, vision on the tower side stream (one-level fork, joined before the grouped
+        weight-gradient launches)."""
+        from .hip import kernels as K
+        d = self._depth
+        cur = torch.cuda.current_stream()
+        side = getattr(self.model, '_tower_stream', None) or torch.cuda.Stream()
+        prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
+        try:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                d['blocks']['V'].resume_backward(to_end=last)
+            d['blocks']['T'].resume_backward(to_end=last)
+            cur.wait_stream(side)
+            K.wgrad_flush_all()
+        finally:
+            K.WGRAD_DEFER_TO_STEP_END = prev_defer
+
     def _segment_T(self):
         self._split_backward('T', (2, 3))            # (text_pooled, text_sequence)
 
@@ -247,6 +299,16 @@ class GraphedTrainStep:
     def _segment_of(self, name):
         import re
         seg = 'V' if name.startswith('visual_encoder.') else 'T' if name.startswith('text_encoder.') else 'H'
+        if self._depth is not None and seg != 'H':
+            m = re.search(r'\.layers?\.(\d+)\.', name)
+            cuts = self._depth['cuts'][seg]                 # descending layer indices: segment j holds layers >= cuts[j] (and < cuts[j-1])
+            if m is None:
+                return f"B{self._depth['n']}"               # embeddings, pre-LayerNorm, patch projection: the last segment
+            l = int(m.group(1))
+            for j, c in enumerate(cuts):
+                if l >= c:
+                    return f'B{j + 1}'
+            return f"B{self._depth['n']}"
         if seg in self._splits:
             m = re.search(r'\.layers?\.(\d+)\.', name)
             if m is None or int(m.group(1)) < self._splits[seg][1]:
@@ -258,6 +320,9 @@ class GraphedTrainStep:
             return 'hip-graph (one graph: 2 parallel encoder branches, grouped weight gradients, clip + AdamW)'
         if not self.segmented:
             return 'hip-graph forward+backward, eager all-reduce, hip-graph optimiser'
+        if self._depth is not None:
+            return (f'{len(self._order) + 2} hip-graphs (encoders fwd | fusion+head fwd+bwd | {self._depth["n"]} depth segments of BOTH encoders\' backward, text and vision as parallel '
+                    f'branches | optimiser); each segment\'s gradient runs all-reduced ({self.reducer.grad_dtype}) in place beside the next segment\'s graph')
         return (f'{len(self._order) + 2} hip-graphs (encoders fwd | fusion+head fwd+bwd | text bwd | vision bwd; encoder backwards cut in {"two" if self._splits else "one"} | optimiser); each block\'s gradient arena '
                 f'all-reduced ({self.reducer.grad_dtype}) beside the next block\'s graph')
 

@@ -168,7 +168,7 @@ class ClipRunner:
             return done.value
 
     def backward_steps(self, saved, dout, split_after):
-        """The backward as a generator: with ``split_after = l`` it yields the gradient dict once layers L-1 .. l are done (their
+        """The backward as a generator: with ``split_after = l`` (or a collection of such layer indices) it yields the gradient dict once layers L-1 .. l are done (their
         LayerNorm partials reduced; their weight-gradient GEMMs queued) and finishes the rest when resumed -- the data-parallel
         captured step puts the two halves into two graphs so that the upper half's gradients travel while the lower half computes
         (graph.GraphedTrainStep).  Returns the gradient dict."""
@@ -180,7 +180,7 @@ class ClipRunner:
         dxb = K.cast_bf16(dx)
         K.colsum_bf16(dxb, M, D, out=G[f'l{self.L - 1}.fc2_b'])          # later layers get it fused into LN1-backward
         for l in reversed(range(self.L)):
-            if split_after is not None and l == split_after - 1 and l >= 0:
+            if split_after is not None and l >= 0 and (l + 1) in ((split_after,) if isinstance(split_after, int) else tuple(split_after)):
                 K.ln_reduce_flush()
                 yield G
             k = f'l{l}.'
@@ -267,7 +267,7 @@ class RobertaRunner:
         dev = dx.device
         _, G = self.arena.alloc(dev)
         for l in reversed(range(self.L)):
-            if split_after is not None and l == split_after - 1 and l >= 0:
+            if split_after is not None and l >= 0 and (l + 1) in ((split_after,) if isinstance(split_after, int) else tuple(split_after)):
                 K.ln_reduce_flush()
                 yield G
             k = f'l{l}.'

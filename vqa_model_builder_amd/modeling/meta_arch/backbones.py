@@ -48,7 +48,7 @@ class _BlockFn(torch.autograd.Function):
 
 
 class _ResumableBackward:
-    """Data-parallel captured step: ``split_backward_after = l`` makes the block's autograd node run only layers L-1 .. l and hand
+    """Data-parallel captured step: ``split_backward_after = l`` (or several such indices, descending) makes the block's autograd node run only layers L-1 .. l and hand
     out the gradient views (the arena slots of the lower layers are filled by ``resume_backward()``, in the next graph of the step,
     so the upper half's gradients travel while the lower half computes: graph.GraphedTrainStep)."""
     split_backward_after = None
@@ -57,7 +57,8 @@ class _ResumableBackward:
     def _run_backward(self, saved, dout):
         if self.split_backward_after is None:
             return self._runner.backward(saved, dout)
-        gen = self._runner.backward_steps(saved, dout, int(self.split_backward_after))
+        at = self.split_backward_after
+        gen = self._runner.backward_steps(saved, dout, int(at) if isinstance(at, int) else tuple(int(a) for a in at))
         try:
             G = next(gen)
             self._pending_backward = gen
@@ -65,12 +66,20 @@ class _ResumableBackward:
             G = done.value
         return G
 
-    def resume_backward(self):
-        gen, self._pending_backward = self._pending_backward, None
+    def resume_backward(self, to_end: bool = True):
+        """Continues the pending backward: to its end (``to_end``, the two-piece split) or to the next split point."""
+        gen = self._pending_backward
         if gen is None:
             return
-        for _ in gen:                               # runs to the end (a single resume point)
-            pass
+        if to_end:
+            self._pending_backward = None
+            for _ in gen:
+                pass
+            return
+        try:
+            next(gen)
+        except StopIteration:
+            self._pending_backward = None
 
 
 def _require_cuda(t, what):
