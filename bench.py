@@ -184,6 +184,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         try:
             graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer, segmented=True if getattr(args, 'force_segmented', False) else None,
                                        moe_branches=1 if args.moe_branches is None else args.moe_branches, dp_split=args.dp_split,
+                                       exchange_on_side_stream=not args.exchange_inline,
                                        capture_error_mode='thread_local' if dist_on else 'global')
         except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
             ok = 0
@@ -371,6 +372,7 @@ def main():
     ap.add_argument('--dp-split', default='depth', choices=['depth', 'towers'],
                     help="how the data-parallel captured step cuts the encoders' backward: 'depth' = up to four depth segments, text and vision layers of a segment as "
                          "parallel branches of one graph (default); 'towers' = text backward then vision backward, each in two graphs")
+    ap.add_argument('--exchange-inline', action='store_true', help='diagnostics: wire-format copies of the gradient exchange on the compute stream (first form of round 2)')
     ap.add_argument('--force-dist', action='store_true',
                     help='diagnostics on a one-GPU box: initialise a ONE-rank RCCL process group and run the N > 1 code path (segmented step, every '
                          'all-reduce / all-gather really issued) -- exercises RCCL, not its performance')

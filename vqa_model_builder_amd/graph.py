@@ -50,7 +50,8 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, batch: Dict[str, torch.Tensor], *, loss_of: Optional[Callable] = None,
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
-                 moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True, dp_split: str = 'depth'):
+                 moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True, dp_split: str = 'depth',
+                 exchange_on_side_stream: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -64,6 +65,7 @@ class GraphedTrainStep:
         ``dp_split`` (segmented step): 'depth' (default) cuts BOTH encoders' backward by depth into up to four graphs B1 .. B4, each
         holding the text and the vision layers of that depth as parallel branches (the two towers keep filling each other's gaps, as in
         the one-graph step); 'towers' is the first form of this round: text backward (T, T2) then vision backward (V, V2), one tower at a time.
+        ``exchange_on_side_stream`` (segmented step): each segment's pack / all-reduce / unpack chain runs on a stream of its own.
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
         ``forward_from_features``): the multi-graph data-parallel step described in the module docstring."""
@@ -105,6 +107,7 @@ class GraphedTrainStep:
                     order.append(seg + '2')
             self._order = tuple(order)
         self._exposed_ms, self._comm_events, self._replays = [], None, 0
+        self._exchange_stream = torch.cuda.Stream() if (self.segmented and exchange_on_side_stream) else None
         self._segment_marks = []
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -354,16 +357,31 @@ class GraphedTrainStep:
         self.g_main.replay()
         if self.segmented:
             red = self.reducer
+            cur = torch.cuda.current_stream()
+            xs = self._exchange_stream
             for i, name in enumerate(order):
                 if timed:
                     marks[1 + i].record()
                 self.graphs[name].replay()
-                self.graphs['pack' + name].replay()
-                red.reduce_segment(name)                 # asynchronous: travels beside the next segment's graph
+                if xs is None:
+                    self.graphs['pack' + name].replay()
+                    red.reduce_segment(name)             # asynchronous: travels beside the next segment's graph
+                else:
+                    # the segment's whole exchange chain -- wire-format copies (fp32 -> bf16), all-reduce / all-gather, copies back into the
+                    # fp32 arenas, scatter of the gathered embedding rows -- leaves the compute stream: ~0.5 ms of copy kernels per step
+                    # (1.2 GB each way with bf16 buckets) run beside the next segment's graph instead of in front of / behind it
+                    xs.wait_stream(cur)
+                    with torch.cuda.stream(xs):
+                        self.graphs['pack' + name].replay()
+                        red.reduce_segment(name)
+                        red.wait_segment(name)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()                                 # all compute of the step is enqueued: what follows is exposed exchange
-            for name in order:
-                red.wait_segment(name)
+            if xs is None:
+                for name in order:
+                    red.wait_segment(name)
+            else:
+                cur.wait_stream(xs)
             ev1.record()
             if timed:
                 marks[len(order) + 1] = ev0
