@@ -184,7 +184,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         try:
             graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer, segmented=True if getattr(args, 'force_segmented', False) else None,
                                        moe_branches=1 if args.moe_branches is None else args.moe_branches, dp_split=args.dp_split,
-                                       exchange_on_side_stream=not args.exchange_inline,
+                                       exchange_on_side_stream=not args.exchange_inline, wire_optimizer=not args.no_wire_optimizer,
                                        capture_error_mode='thread_local' if dist_on else 'global')
         except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
             ok = 0
@@ -372,6 +372,7 @@ def main():
     ap.add_argument('--dp-split', default='depth', choices=['depth', 'towers'],
                     help="how the data-parallel captured step cuts the encoders' backward: 'depth' = up to four depth segments, text and vision layers of a segment as "
                          "parallel branches of one graph (default); 'towers' = text backward then vision backward, each in two graphs")
+    ap.add_argument('--no-wire-optimizer', action='store_true', help='diagnostics: copy the all-reduced bf16 sums back into the fp32 gradient arenas before the optimiser (first form of round 2)')
     ap.add_argument('--exchange-inline', action='store_true', help='diagnostics: wire-format copies of the gradient exchange on the compute stream (first form of round 2)')
     ap.add_argument('--force-dist', action='store_true',
                     help='diagnostics on a one-GPU box: initialise a ONE-rank RCCL process group and run the N > 1 code path (segmented step, every '
@@ -493,15 +494,18 @@ def main():
                 for k in blocks:
                     ready += sm.get(k, 0.0)
                     dense = sb.get(k, 0) - sg.get(k, 0)              # measured at world 1: the gather part counted once
-                    end = max(ready, end) + (2 * (7 / 8) * dense * wire + 7 * sg.get(k, 0)) / BUS * 1e3      # ring all-reduce + all-gather of 8 ranks' rows
+                    pack = (dense / 4) * 6 / 5.0e12 * 1e3 if wire < 1.0 else 0.0          # bf16 buckets: fp32 -> bf16 staging copy (4 B read + 2 B written per element, ~5 TB/s), on the exchange stream
+                    end = max(ready, end) + pack + (2 * (7 / 8) * dense * wire + 7 * sg.get(k, 0)) / BUS * 1e3      # ring all-reduce + all-gather of 8 ranks' rows
                 exposed = max(0.0, end - ready)
                 step = ready + exposed + t_opt
                 return {'exposed_allreduce_ms': round(exposed, 3), 'ms_per_step': round(step, 3), 'scaling_vs_1gpu': round(8 * main_res['ms_per_step'] / step, 2)}
             dp_model = {'segmented_step_ms_1gpu': total, 'segment_ms_1gpu': sm, 'optimizer_ms': round(t_opt, 3), 'segment_bytes_fp32': sb,
                         'assumed_bus_GBps': BUS / 1e9, 'predicted_8gpu_fp32_buckets': predict(1.0), 'predicted_8gpu_bf16_buckets': predict(0.5),
-                        'note': 'compute = the graphs of the segmented step measured on one GPU (no exchange); exchange = ring all-reduce of each '
-                                'block behind one RCCL stream, started when the block\'s graph is done; the xGMI bus bandwidth is an ASSUMPTION, not '
-                                'a measurement -- the driver\'s N = 8 run is the measurement'}
+                        'note': 'compute = the graphs of the segmented step measured on one GPU (no exchange); exchange = per segment, on the exchange stream: '
+                                '(bf16 buckets) the fp32 -> bf16 staging copy, then the ring all-reduce, started when the segment\'s graph is done and the previous '
+                                'segment\'s exchange is through; the optimiser reads the bf16 sums in place.  The xGMI bus bandwidth is an ASSUMPTION, not '
+                                'a measurement -- the driver\'s N = 8 run is the measurement.  Measured with a ONE-rank RCCL group (bench.py --force-dist): '
+                                'profiles/r02/rccl_one_rank_bench_*.log'}
         except Exception as e:                       # noqa: BLE001
             args.force_segmented = False
             dp_model = {'error': f'{type(e).__name__}: {e}'}

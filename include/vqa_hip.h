@@ -311,6 +311,8 @@ int vqa_adamw_step(const VqaAdamWDesc* d, vqa_stream_t s);
  *                  (torch.nn.utils.clip_grad_norm_, training_pipeline.py:497), then the AdamW update with the job's own
  *                  weight_decay (param groups of training_pipeline.py:239-252); shadow != NULL: also writes the
  *                  parameter's bf16 (shadow_kind 0) or packed-fp32 (shadow_kind 1) copy the GEMMs read. */
+#define VQA_OPT_GRAD_BF16 0x100u  /* VqaOptJob::shadow_kind flag: ``grad`` points at bfloat16 values (the data-parallel exchange's wire format: the
+                                   * all-reduced sums are consumed where RCCL left them, no copy back into the fp32 gradient); low byte = kind */
 typedef struct VqaOptJob {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq; void* shadow;
     uint64_t n; float weight_decay; uint32_t shadow_kind;

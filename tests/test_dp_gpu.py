@@ -101,10 +101,11 @@ def _train_worker(rank, world, port, q, mode):
                               grad_dtype='bf16' if 'bf16' in mode else 'fp32')
             opt.grad_prescale = 1.0 / world
             gs = GraphedTrainStep(model, opt, batch, reducer=red, warmup=warm, capture_error_mode='thread_local',
-                                  segmented=False if 'flat' in mode else None, dp_split='towers' if 'towers' in mode else 'depth')
+                                  segmented=False if 'flat' in mode else None, dp_split='towers' if 'towers' in mode else 'depth',
+                                  wire_optimizer='nowire' not in mode)
             losses = [float('nan')] * warm + [gs(batch).item() for _ in range(n - warm)]
             torch.cuda.synchronize()
-            info = dict(segmented=gs.segmented, stats=gs.comm_stats(), describe=gs.describe(),
+            info = dict(segmented=gs.segmented, stats=gs.comm_stats(), describe=gs.describe(), wired=len(opt.wire_grads or {}),
                         sparse=sum(len(sg.get('sparse', [])) for sg in getattr(red, '_segments', {}).values()))
         torch.cuda.synchronize()
         sig = float(sum(p.detach().double().abs().sum().item() for p in params))
@@ -130,11 +131,12 @@ def _run_two(mode):
     return res
 
 
-@pytest.mark.parametrize('mode,tol', [('graph', 1e-4), ('graph_towers', 1e-4), ('graph_flat', 1e-4), ('graph_bf16', 2e-3)])
+@pytest.mark.parametrize('mode,tol', [('graph', 1e-4), ('graph_towers', 1e-4), ('graph_flat', 1e-4), ('graph_bf16', 2e-3), ('graph_bf16_nowire', 2e-3)])
 def test_graphed_data_parallel_step_matches_eager_data_parallel_step(mode, tol):
     """'graph': the depth-segmented step (encoders fwd | fusion+head fwd+bwd | B1 .. Bn: the text AND vision layers of one depth range as parallel branches
     of one graph | optimiser) with every segment's gradient runs all-reduced beside the next segment's graph; 'graph_towers': one tower at a time (text bwd upper half |
-    lower half | vision bwd upper | lower); 'graph_flat': round 1's forward+backward graph -> exchange -> optimiser
+    lower half | vision bwd upper | lower); 'graph_bf16': bfloat16 buckets, the optimiser reading the summed gradients in the exchange's staging buffers
+    ('graph_bf16_nowire': copied back into the fp32 arenas first); 'graph_flat': round 1's forward+backward graph -> exchange -> optimiser
     graph; 'graph_bf16': bfloat16 gradient buckets on the wire.  All against the eager step with hook-overlapped buckets."""
     eager, graph = _run_two('eager'), _run_two(mode)
     assert graph[0][2]['segmented'] == (mode != 'graph_flat'), graph[0][2]
@@ -144,6 +146,7 @@ def test_graphed_data_parallel_step_matches_eager_data_parallel_step(mode, tol):
         assert set(st['segment_bytes']) == segs and st['exposed_comm_ms'] >= 0.0, st
         assert set(st['segment_ms']) == segs | {'F'}, st
         assert graph[0][2]['sparse'] == 1                  # the word-embedding gradient travelled as gathered (ids, rows)
+        assert (graph[0][2]['wired'] > 100) == (mode == 'graph_bf16'), graph[0][2]['wired']     # every all-reduced parameter read on the wire, or none
         assert min(st['segment_bytes'].values()) > 0, st
     for r in (0, 1):
         le, lg = eager[r][0], graph[r][0]

@@ -223,19 +223,27 @@ __global__ void adamw_kernel(const VqaAdamWDesc d) {
 // bias both keep the whole chip streaming (a per-tensor grid would leave the big tensors to a handful of workgroups).
 constexpr uint32_t OPT_CHUNK = 65536;
 
+// Gradients in the data-parallel WIRE format (VQA_OPT_GRAD_BF16 in VqaOptJob::shadow_kind): ``grad`` then points at bfloat16 values -- the
+// all-reduced sums as RCCL left them in the exchange's staging buffer -- whatever the library's own 16-bit operand type is.
+__device__ __forceinline__ float wire_bf16(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ f32x4 wire_bf16x4(const void* base, uint64_t i) {
+    const u16x4 b = *reinterpret_cast<const u16x4*>(reinterpret_cast<const uint16_t*>(base) + i);
+    return (f32x4){wire_bf16(b[0]), wire_bf16(b[1]), wire_bf16(b[2]), wire_bf16(b[3])};
+}
 __global__ void sumsq_multi_kernel(const VqaOptJob* __restrict__ jobs, const uint32_t* __restrict__ chunks, float* __restrict__ norm2) {
     __shared__ float red[4];
     const VqaOptJob j = jobs[chunks[2 * blockIdx.x]];
     const uint64_t beg = chunks[2 * blockIdx.x + 1];
     const uint64_t end = beg + OPT_CHUNK < j.n ? beg + OPT_CHUNK : j.n;
     const float* g = j.grad;
+    const bool g16 = (j.shadow_kind & VQA_OPT_GRAD_BF16) != 0;
     float acc = 0.f;
     const uint64_t e4 = beg + (end - beg) / 4 * 4;
     for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+        const f32x4 v = g16 ? wire_bf16x4(g, i) : *reinterpret_cast<const f32x4*>(g + i);
         acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    for (uint64_t i = e4 + threadIdx.x; i < end; i += blockDim.x) acc += g[i] * g[i];
+    for (uint64_t i = e4 + threadIdx.x; i < end; i += blockDim.x) { const float t = g16 ? wire_bf16(reinterpret_cast<const uint16_t*>(g)[i]) : g[i]; acc += t * t; }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -276,6 +284,8 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
     if (norm2 && max_norm > 0.f) { const float c = max_norm / (prescale * sqrtf(norm2[0]) + 1e-6f); gs = c < 1.f ? c * prescale : prescale; }
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * j.weight_decay;
     const uint64_t e4 = beg + (end - beg) / 4 * 4;
+    const bool g16 = (j.shadow_kind & VQA_OPT_GRAD_BF16) != 0;
+    const uint32_t skind = j.shadow_kind & 0xffu;
 #ifndef VQA_ADAMW_NT
 #define VQA_ADAMW_NT 1
 #endif
@@ -292,7 +302,7 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
 #pragma unroll VQA_ADAMW_UNROLL
     for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
         f32x4 p = VQA_LD4(j.param + i);
-        const f32x4 g = VQA_LD4(j.grad + i) * gs;
+        const f32x4 g = (g16 ? wire_bf16x4(j.grad, i) : VQA_LD4(j.grad + i)) * gs;
         f32x4 m = VQA_LD4(j.exp_avg + i);
         f32x4 v = VQA_LD4(j.exp_avg_sq + i);
 #pragma unroll
@@ -306,18 +316,18 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
         VQA_ST4(j.exp_avg + i, m);
         VQA_ST4(j.exp_avg_sq + i, v);
         if (j.shadow) {
-            if (j.shadow_kind == 0) { h16x4 o; for (int k = 0; k < 4; ++k) o[k] = (h16_t)p[k]; *reinterpret_cast<h16x4*>((h16_t*)j.shadow + i) = o; }
+            if (skind == 0) { h16x4 o; for (int k = 0; k < 4; ++k) o[k] = (h16_t)p[k]; *reinterpret_cast<h16x4*>((h16_t*)j.shadow + i) = o; }
             else *reinterpret_cast<f32x4*>((float*)j.shadow + i) = p;
         }
     }
     for (uint64_t i = e4 + threadIdx.x; i < end; i += blockDim.x) {
         float p = j.param[i] * decay;
-        const float g = j.grad[i] * gs;
+        const float g = (g16 ? wire_bf16(reinterpret_cast<const uint16_t*>(j.grad)[i]) : j.grad[i]) * gs;
         const float m = beta1 * j.exp_avg[i] + (1.f - beta1) * g;
         const float v = beta2 * j.exp_avg_sq[i] + (1.f - beta2) * g * g;
         p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
         j.param[i] = p; j.exp_avg[i] = m; j.exp_avg_sq[i] = v;
-        if (j.shadow) { if (j.shadow_kind == 0) ((h16_t*)j.shadow)[i] = (h16_t)p; else ((float*)j.shadow)[i] = p; }
+        if (j.shadow) { if (skind == 0) ((h16_t*)j.shadow)[i] = (h16_t)p; else ((float*)j.shadow)[i] = p; }
     }
 }
 

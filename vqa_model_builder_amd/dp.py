@@ -271,7 +271,7 @@ class GradReducer:
                         continue
                     us = p.grad.untyped_storage()
                     by_storage.setdefault(us.data_ptr(), [us, []])[1].append(p)
-            inplace, loose = [], []
+            inplace, loose, where = [], [], []
             for us, ps in by_storage.values():
                 g0 = ps[0].grad
                 if len(ps) > 1 and all(q.grad.dtype == torch.float32 and q.grad.is_contiguous() for q in ps) and us.nbytes() % 4 == 0:
@@ -287,6 +287,10 @@ class GradReducer:
                         else:
                             runs.append([a, e])
                     inplace.extend(whole[a:e] for a, e in runs)
+                    for q in ps:                                  # which run holds each gradient, and where: for wire_gradient_ptrs()
+                        for ri, (a, e) in enumerate(runs):
+                            if a <= q.grad.storage_offset() < e:
+                                where.append((q, len(inplace) - len(runs) + ri, q.grad.storage_offset() - a))
                 else:
                     loose.extend(ps)
             pack = None
@@ -299,6 +303,7 @@ class GradReducer:
                     srcs.append(q.grad.reshape(-1))
                     dsts.append(view)
                     q.grad = view.view(q.shape)
+                    where.append((q, len(inplace), off))
                     off += (q.numel() + 3) // 4 * 4
                 pack = (flat, dsts, srcs)
                 inplace.append(flat)
@@ -311,8 +316,27 @@ class GradReducer:
                 _, ids, rows, _ = getter()
                 gather += rows.numel() * 4 + ids.numel() * 4          # per rank; every rank receives world x this
             nbytes += self.world * gather
-            self._segments[name] = {'flats': inplace, 'pack': pack, 'stage': stage, 'works': [], 'bytes': nbytes, 'sparse': sparse_here, 'gathered': [], 'gather_bytes_per_rank': gather}
+            self._segments[name] = {'flats': inplace, 'pack': pack, 'stage': stage, 'works': [], 'bytes': nbytes, 'sparse': sparse_here, 'gathered': [], 'gather_bytes_per_rank': gather,
+                                    'where': where}
         self._inplace = [f for s in self._segments.values() for f in s['flats']]
+        return self
+
+    def wire_gradient_ptrs(self) -> Dict[int, int]:
+        """bf16 buckets: id(parameter) -> device address of the parameter's gradient inside the segment's bfloat16 staging buffer (what the
+        all-reduce leaves there IS the summed gradient).  An optimiser that reads it there (FusedAdamW.wire_grads) makes the copy back into
+        the fp32 arenas unnecessary: call ``consume_on_wire()`` and ``wait_segment`` skips it -- 1.2 GB of copy traffic per step at 244 M
+        parameters, and the optimiser's two gradient reads shrink from 4 to 2 bytes per parameter.  ``p.grad`` then keeps the LOCAL
+        gradient of the step (nobody reads it in the captured step)."""
+        out = {}
+        for seg in (self._segments or {}).values():
+            if seg['stage'] is None:
+                continue
+            for q, fi, off in seg['where']:
+                out[id(q)] = seg['stage'][fi].data_ptr() + 2 * off
+        return out
+
+    def consume_on_wire(self, on: bool = True):
+        self._consume_on_wire = bool(on)
         return self
 
     def pack_segment(self, name: str):
@@ -352,7 +376,7 @@ class GradReducer:
         for w in seg['works']:
             w.wait()
         seg['works'] = []
-        if seg['stage'] is not None:
+        if seg['stage'] is not None and not getattr(self, '_consume_on_wire', False):
             for f, s in zip(seg['flats'], seg['stage']):
                 f.copy_(s)                                   # bf16 sum -> the fp32 arena the optimiser reads
         if seg['gathered']:

@@ -51,7 +51,7 @@ class GraphedTrainStep:
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
                  moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True, dp_split: str = 'depth',
-                 exchange_on_side_stream: bool = True):
+                 exchange_on_side_stream: bool = True, wire_optimizer: bool = True):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -66,6 +66,8 @@ class GraphedTrainStep:
         holding the text and the vision layers of that depth as parallel branches (the two towers keep filling each other's gaps, as in
         the one-graph step); 'towers' is the first form of this round: text backward (T, T2) then vision backward (V, V2), one tower at a time.
         ``exchange_on_side_stream`` (segmented step): each segment's pack / all-reduce / unpack chain runs on a stream of its own.
+        ``wire_optimizer`` (segmented step, bf16 buckets, FusedAdamW): the optimiser reads the summed bfloat16 gradients in the exchange's
+        staging buffers; ``p.grad`` keeps the rank's local gradient.
         ``moe_branches``: MoE experts on side streams = parallel branches of the capture (0 off, 1 the specialised experts, 2 all).
         ``segmented`` (default: with a reducer whose world > 1 and a model that offers ``encode_both`` /
         ``forward_from_features``): the multi-graph data-parallel step described in the module docstring."""
@@ -174,6 +176,10 @@ class GraphedTrainStep:
                 with torch.cuda.graph(g, pool=pool, **kw):
                     reducer.pack_segment(name)
                 self.graphs['pack' + name] = g
+            if wire_optimizer and getattr(reducer, 'grad_dtype', 'fp32') == 'bf16' and hasattr(self.opt, 'wire_grads') and not getattr(reducer, 'average', False):
+                # bf16 buckets: the optimiser reads the all-reduced bfloat16 sums where RCCL leaves them (no copy back into the fp32 arenas)
+                self.opt.wire_grads = reducer.wire_gradient_ptrs()
+                reducer.consume_on_wire(True)
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=pool, **kw):
                 self.opt.step()

@@ -40,6 +40,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper = None                                # HIP-graph mode: per group device floats {lr, step}
         self._staging = {}                                # HIP-graph mode: pinned host rows per job table
         self.grad_prescale = 1.0                          # DP: gradients hold the all-reduced SUM; 1/world is applied here
+        self.wire_grads = None                            # DP captured step with bf16 buckets: id(parameter) -> device address of its all-reduced
+                                                          # bfloat16 gradient in the exchange's staging buffer (read there: no copy back to fp32)
 
     def attach_shadows(self, model):
         """Lets the update kernel write the bf16 / packed-fp32 weight shadows of the block runners directly."""
@@ -149,13 +151,19 @@ class FusedAdamW(torch.optim.Optimizer):
                 if self._hyper is None:                     # capturable mode counts on the device (bias corrections come from there)
                     state['step'] = prev_step + 1
                 sp, sk, _ = shadows.get(id(p), (0, 0, None))
+                gptr = g.data_ptr()
+                wire = self.wire_grads.get(id(p)) if self.wire_grads else None
+                if wire is not None:                        # data-parallel captured step: the all-reduced bf16 sum, where RCCL left it (dp.py)
+                    gptr, wire_flag = wire, 0x100           # VQA_OPT_GRAD_BF16
+                else:
+                    wire_flag = 0
                 updated.add(id(p))
                 if sp == 0:                                 # stand-alone parameter (tail ops, experts): its cached bf16 copy, if any
                     sh = _ops.standalone_shadow(p)
                     if sh is not None and sh.numel() == p.numel():
                         sp, sk = sh.data_ptr(), 0
                         standalone.append(p)
-                wd_kind = struct.unpack('<q', struct.pack('<fI', float(group['weight_decay']), sk))[0]
+                wd_kind = struct.unpack('<q', struct.pack('<fI', float(group['weight_decay']), sk | wire_flag))[0]
                 act = getattr(p, '_vqa_active', None)       # device word: routed-token count of the parameter's expert (dense MoE dispatch)
                 own = getattr(p, '_vqa_step', None)         # device word: the expert's own update count (bias corrections)
                 if own is not None:
@@ -165,7 +173,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         ent = counted[id(s_all)] = (a_all, s_all, {})
                     ent[2].setdefault(e, prev_step)
                 launches.setdefault((gi, state['step']), []).append(
-                    (p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
+                    (p.data_ptr(), gptr, state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
                      act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0))
                 dev = p.device
         if not launches:
