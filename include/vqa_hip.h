@@ -98,6 +98,9 @@ int vqa_colsum_bf16(const void* x, int M, int N, int ld, float* out, vqa_stream_
 int vqa_colsum_f32(const float* x, int M, int N, int ld, float* out, vqa_stream_t s);
 /* y = a + b (fp32), optional bf16 copy */
 int vqa_add_f32(const float* a, const float* b, float* y, void* y_bf16, size_t n, vqa_stream_t s);
+/* Reads nbytes (16-byte aligned start) once with `workgroups` (0 => 64) workgroups and discards them: pulls a span of weights through the
+ * memory-side cache ahead of the GEMMs that will read it (run it on a side stream, one layer ahead).  Replaces nothing in the reference. */
+int vqa_prefetch(const void* p, size_t nbytes, int workgroups, vqa_stream_t s);
 /* out = dy * act'(pre) * dropout_mask(index)  -- backward of y = dropout(act(pre)) outside a GEMM epilogue
  * (vqa_model.py:458-459 ReLU+Dropout, expert FFNs).  pre may be NULL (no activation). */
 int vqa_act_drop_bwd(const float* dy, const void* pre_bf16, int act, float* out, void* out_bf16, size_t n, float p, uint64_t seed,

@@ -196,9 +196,11 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
+            K.prefetch_begin()                          # the weight-prefetch stream: a one-level fork of the capture stream (kernels.py)
             out = self.model(**self.static)
             loss = self.loss_of(out)
             self._backward(loss)
+            K.prefetch_join()
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
@@ -209,7 +211,10 @@ class GraphedTrainStep:
         _blocks.advance_rng_epoch()
         self.opt.zero_grad(set_to_none=True)
         s = self.static
+        from .hip import kernels as K
+        K.prefetch_begin()
         self._enc = self.model.encode_both(s['pixel_values'], s['input_ids'], s['attention_mask'])
+        K.prefetch_join()
 
     def _segment_H(self):
         from .hip import kernels as K
@@ -232,8 +237,10 @@ class GraphedTrainStep:
         pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
         prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
+            K.prefetch_begin()
             if pairs:
                 torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+            K.prefetch_join()
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
@@ -252,7 +259,9 @@ class GraphedTrainStep:
         from .hip import kernels as K
         prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
+            K.prefetch_begin()
             self._splits[seg][0].resume_backward()      # ... and the lower half + embeddings run here
+            K.prefetch_join()
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer
@@ -284,11 +293,13 @@ class GraphedTrainStep:
         side = getattr(self.model, '_tower_stream', None) or torch.cuda.Stream()
         prev_defer, K.WGRAD_DEFER_TO_STEP_END = K.WGRAD_DEFER_TO_STEP_END, self._defer_wgrad
         try:
+            K.prefetch_begin()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 d['blocks']['V'].resume_backward(to_end=last)
             d['blocks']['T'].resume_backward(to_end=last)
             cur.wait_stream(side)
+            K.prefetch_join()
             K.wgrad_flush_all()
         finally:
             K.WGRAD_DEFER_TO_STEP_END = prev_defer

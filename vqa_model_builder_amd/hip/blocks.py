@@ -132,6 +132,7 @@ def _q_kv_attention(xqb, xkvb, w_in, b_in, B, H, Sq, Skv, D, mask_u8, drop):
 
 class ClipRunner:
     """W: object with .p(key)->fp32 parameter tensor and .s(key)->bf16/fp32 shadow view (see modeling.backbones)."""
+    WEIGHTS = ('qkv_w', 'out_w', 'fc1_w', 'fc2_w')          # a layer's 16-bit weights: one contiguous span of the block's shadow arena
 
     def __init__(self, W, num_layers, D, heads, inter, patch, eps=1e-5):
         self.W, self.L, self.D, self.H, self.I, self.ps, self.eps = W, num_layers, D, heads, inter, patch, eps
@@ -149,6 +150,8 @@ class ClipRunner:
         saved = dict(B=B, P=P, xp=xp, u=u, mean0=mean0, rstd0=rstd0, layers=[])
         for l in range(self.L):
             k = f'l{l}.'
+            if l + 1 < self.L:                             # the next layer's weights leave HBM while this layer computes (kernels.prefetch_weights)
+                K.prefetch_weights([W.s(f'l{l + 1}.{n}') for n in self.WEIGHTS])
             _, h1, m1, r1 = K.layernorm_fwd(x, W.p(k + 'ln1.w'), W.p(k + 'ln1.b'), M, D, want_f32=False, want_bf16=True, eps=self.eps)
             qkv, ctx = _qkv_attention(h1, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), B, H, T, D, None, NO_DROP, K.FUSED_ATTENTION_ENCODERS)
             x1, _, _ = K.linear_fwd(ctx, W.s(k + 'out_w'), W.p(k + 'out_b'), M, D, D, want_f32=True, residual=x)
@@ -184,6 +187,8 @@ class ClipRunner:
                 K.ln_reduce_flush()
                 yield G
             k = f'l{l}.'
+            if l > 0:
+                K.prefetch_weights([W.s(f'l{l - 1}.{n}') for n in self.WEIGHTS])
             x, h1, m1, r1, qkv, ctx, x1, h2, m2, r2, a, g = saved['layers'][l]
             K.linear_dw(dxb, g, M, D, I, out=G[k + 'fc2_w'], prezeroed=False)
             _, da = K.linear_dx(dxb, W.s(k + 'fc2_w'), M, D, I, want_bf16=True, act_grad_of=a, act_bwd=K.ACT_QUICK_GELU, colsum=G[k + 'fc1_b'])
@@ -219,6 +224,7 @@ class ClipRunner:
 
 class RobertaRunner:
     last_embed_rows = None
+    WEIGHTS = ('qkv_w', 'ao_w', 'i_w', 'o_w')               # a layer's 16-bit weights: one contiguous span of the block's shadow arena
 
     def __init__(self, W, num_layers, D, heads, inter, pad_id=1, hidden_drop=0.1, attn_drop=0.1, eps=1e-5):
         self.W, self.L, self.D, self.H, self.I = W, num_layers, D, heads, inter
@@ -240,6 +246,8 @@ class RobertaRunner:
         for l in range(self.L):
             k = f'l{l}.'
             st = 8 * (l + 1)
+            if l + 1 < self.L:
+                K.prefetch_weights([W.s(f'l{l + 1}.{n}') for n in self.WEIGHTS])
             qkv, ctx = _qkv_attention(xb, W.s(k + 'qkv_w'), W.s(k + 'qkv_b'), B, H, S, D, kpm, Drop(pa, seed, st), K.FUSED_ATTENTION_ENCODERS)
             s1, _, _ = K.linear_fwd(ctx, W.s(k + 'ao_w'), W.p(k + 'ao_b'), M, D, D, want_f32=True, residual=x, drop=Drop(pd, seed, st + 1))
             x1, x1b, m1, r1 = K.layernorm_fwd(s1, W.p(k + 'ao_ln.w'), W.p(k + 'ao_ln.b'), M, D, want_bf16=True, eps=self.eps)
@@ -272,6 +280,8 @@ class RobertaRunner:
                 yield G
             k = f'l{l}.'
             st = 8 * (l + 1)
+            if l > 0:
+                K.prefetch_weights([W.s(f'l{l - 1}.{n}') for n in self.WEIGHTS])
             xb, qkv, ctx, s1, m1, r1, x1b, a, g, s2, m2, r2 = saved['layers'][l]
             # output LayerNorm:  x2 = LN(s2),  s2 = x1 + drop(dense(g));  bias grad of `dense` = colsum of the masked ds2
             ds2, ds2b, _, _ = K.layernorm_bwd(dx, s2, m2, r2, W.p(k + 'o_ln.w'), M, D, want_bf16=True, drop=Drop(pd, seed, st + 2), drop_mode=1,

@@ -41,6 +41,65 @@ def L():
     return _l.load()
 
 
+# ---- weight prefetch (one layer ahead, on a stream of its own): MEASURED, OFF ------------------------------------------------------
+# profiles/r02/gemm_cold_weights.log: every GEMM of the step reads its weights from HBM (nothing survives in the Infinity Cache between two
+# uses) and pays +2 - 4 us for it; one streaming reader in front gives most of that back.  ``prefetch_weights`` is called by the block
+# runners at the start of a layer with the NEXT layer's weight views and reads them once (vqa_prefetch) on the prefetch stream.  Inside a
+# HIP-graph capture that stream is a ONE-level fork of the capture stream (profiles/r02/nested_fork_capture.md): ``prefetch_begin()`` (on
+# the capture stream, before any tower forks) and ``prefetch_join()`` bracket every captured region.
+# Result on MI355X (profiles/r02/weight_prefetch.md; cfg2, one box, captured step 7.14 - 7.17 ms without):
+#   * gated (every prefetch waits for an event of the layer before it: exactly one layer ahead)   9.12 ms: the 48 cross-branch edges
+#     serialise the graph's branches (the eager GEMM sum does improve: 5.56 -> 5.40 ms);
+#   * self-paced (no edge; the kernel's width sets its pace: 4 / 8 / 12 / 16 / 24 / 48 workgroups)  8.73 / 7.97 / 7.82 / 7.64 / 7.54 / 7.38 ms:
+#     narrow kernels outlast the region they were forked in, wide ones run layers ahead of the compute and are evicted again.
+# So the cold-weight cost stays; what would remove it is a prefetch INSIDE the compute chain (e.g. the LayerNorm kernels reading the next
+# GEMMs' weights), worth ~5 us per layer and direction at best.  Kept as an option for eager, single-stream use.
+WEIGHT_PREFETCH = False
+PREFETCH_GATED = True
+PREFETCH_WORKGROUPS = 48
+_prefetch_stream = None
+_prefetch_live = False
+
+
+def _pf_stream():
+    global _prefetch_stream
+    if _prefetch_stream is None:
+        _prefetch_stream = torch.cuda.Stream()
+    return _prefetch_stream
+
+
+def prefetch_begin():
+    global _prefetch_live
+    if not WEIGHT_PREFETCH:
+        return
+    _pf_stream().wait_stream(torch.cuda.current_stream())
+    _prefetch_live = True
+
+
+def prefetch_join():
+    global _prefetch_live
+    if _prefetch_live:
+        torch.cuda.current_stream().wait_stream(_pf_stream())
+    _prefetch_live = False
+
+
+def prefetch_weights(tensors, workgroups=64):
+    """``tensors``: views into ONE arena (a layer's 16-bit weights): the span from the lowest to the highest address is read once."""
+    if not WEIGHT_PREFETCH or not tensors:
+        return
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and not _prefetch_live:
+        return                                            # a capture that did not fork the prefetch stream: skip (never fork from a branch)
+    lo = min(t.data_ptr() for t in tensors) & ~15
+    hi = max(t.data_ptr() + t.numel() * t.element_size() for t in tensors)
+    ps = _pf_stream()
+    if PREFETCH_GATED or not capturing:
+        ev = torch.cuda.Event()
+        ev.record()
+        ps.wait_event(ev)
+    _chk(L().vqa_prefetch(lo, hi - lo, workgroups if PREFETCH_GATED else PREFETCH_WORKGROUPS, ps.cuda_stream), 'vqa_prefetch')
+
+
 _gd = _l.VqaGemmDesc()
 _ad = _l.VqaAttnDesc()
 _fd = _l.VqaFusedAttnDesc()

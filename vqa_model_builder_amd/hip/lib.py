@@ -66,6 +66,7 @@ SIGNATURES = {
     'vqa_colsum_bf16': (i32, [vp, i32, i32, i32, vp, vp]),
     'vqa_colsum_f32': (i32, [vp, i32, i32, i32, vp, vp]),
     'vqa_add_f32': (i32, [vp, vp, vp, vp, sz, vp]),
+    'vqa_prefetch': (i32, [vp, sz, i32, vp]),
     'vqa_act_drop_bwd': (i32, [vp, vp, i32, vp, vp, sz, f32, u64, u32, vp]),
     'vqa_gather_rows_f32': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'vqa_patchify_bf16': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
