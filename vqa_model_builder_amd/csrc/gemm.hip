@@ -63,6 +63,8 @@ struct GemmArgs {
     int tiles_n; unsigned tiles_n_magic;    // tile columns of the launch's tile shape and ceil(2^32 / tiles_n) (0 when tiles_n == 1): the
                                             // tile-id -> (row, column) split costs one multiply instead of a ~40-instruction integer division
     float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
+    int tiles_m_cm; unsigned tiles_m_magic; // > 0: COLUMN-major tile order (tile rows of the launch, and ceil(2^32 / tiles_m)): with the XCD remap every XCD then owns
+                                            // a range of output COLUMNS, i.e. every weight line is fetched by ONE XCD (and the activations by all eight)
     int epi_dma;                            // epilogue operand staged through LDS by DMA (ring kernels): 0 none, 1 act_grad_of, 2 residual (host: alignment)
 #ifdef VQA_GEMM_TRACE
     unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
@@ -566,7 +568,8 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     int tm, tn;
-    tile_from_linear(p.tiles_n, p.tiles_n_magic, tile_linear, tm, tn);
+    if (p.tiles_m_cm > 0) tile_from_linear(p.tiles_m_cm, p.tiles_m_magic, tile_linear, tn, tm);
+    else tile_from_linear(p.tiles_n, p.tiles_n_magic, tile_linear, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -1007,6 +1010,7 @@ int g_ws_mode = 0;          // 0: off (default); 1: auto (ws_pick); 2 + i: force
 unsigned g_ws_mask = 0xffffffffu;   // auto mode: bit i allows WS_TILES[i]
 
 int g_force_cfg = -1, g_force_stages = 2;
+int g_tile_order = 0;      // 0 / 1: row-major tile ids (default: an XCD owns rows of the output: activations fetched once, weights by every XCD); 2: column-major (lab, see vqa_gemm_bf16)
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
@@ -1166,6 +1170,7 @@ extern "C" void vqa_set_gemm_ws(int mode) { if (mode >= 0x100) { g_ws_mode = 1; 
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
 extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }
+extern "C" void vqa_set_gemm_tile_order(int order) { g_tile_order = order; }
 extern "C" void vqa_set_gemm_pipeline(int v1) {
     // diagnostics for tile_hint launches.  0: register-staged double buffer; 2 / 3: LDS-DMA ring with that many stages
     g_use_v1 = v1 != 0; g_force_dma = v1 != 0;
@@ -1241,6 +1246,13 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : cfg == 7 ? 32 : cfg == 8 ? 64 : 128;
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
     p.tiles_n = ceil_div(d->N, bn); p.tiles_n_magic = div_magic(p.tiles_n);
+    p.tiles_m_cm = 0; p.tiles_m_magic = 0;
+    // Column-major tile ids (vqa_set_gemm_tile_order(2)): under the XCD remap every XCD then owns a range of output COLUMNS, so every line of
+    // the weight operand is fetched from HBM by one XCD instead of missing in eight L2s at once.  MEASURED, NOT ADOPTED (profiles/r02/gemm_tile_order.log):
+    // launch by launch with weights streamed from HBM it wins on every shape (2048x2304x768 19.8 -> 16.1 us, dX 2048x3072x768 21.7 -> 18.3) -- but
+    // that microbenchmark re-uses ONE activation buffer, warm in all eight L2s; in the step the activations were just written by the previous
+    // kernel and every XCD now pulls all of them through the fabric: cfg2 7.21 -> 7.43 ms, GEMM sum 5.63 -> 5.92 ms, cfg3 9.72 -> 9.87 (one box).
+    if (g_tile_order == 2 && ceil_div(d->M, bm) > 1) { p.tiles_m_cm = ceil_div(d->M, bm); p.tiles_m_magic = div_magic(p.tiles_m_cm); }
 
     int splits = d->split_k;
     const bool can_split = d->c_f32 && !d->c_bf16 && !d->pre_bf16 && !d->bias && !d->residual && !d->act_grad_of &&

@@ -112,6 +112,7 @@ SIGNATURES = {
     'vqa_set_gemm_group_persistent': (None, [i32]),
     'vqa_set_gemm_grid_cap': (None, [i32]),
     'vqa_set_gemm_force': (None, [i32, i32]),
+    'vqa_set_gemm_tile_order': (None, [i32]),
     'vqa_layernorm_bwd_blocks': (i32, [i32]),
     'vqa_set_layernorm_bwd_blocks': (None, [i32]),
     'vqa_layernorm_bwd_partials': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, u64, u32, i32, vp]),
