@@ -79,6 +79,29 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
                                                f32x4 (&pn)[KT], f32x4 (&ks)[KT], int q0 = 0) {
     constexpr int PITCH = DH * 2 + 16;
     const int g = lane >> 4;
+    // key-padding mask bytes of this lane's keys (kv = 16t + 4g + r), fetched BEFORE the score MFMAs: read one by one where they are used,
+    // each byte was its own dependent L2 round trip behind a branch -- 16 of them per wave (ISA of round 2: G [vmcnt(0)] x 16)
+    uint32_t mw[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) mw[t] = 0u;
+    if (a.mask) {
+        const unsigned char* mrow = a.mask + (size_t)b * a.Skv;
+        if ((a.Skv & 3) == 0) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const int kv0 = 16 * t + 4 * g;
+                if (kv0 < a.Skv) mw[t] = *reinterpret_cast<const uint32_t*>(mrow + kv0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kv = 16 * t + 4 * g + r;
+                    if (kv < a.Skv) mw[t] |= (uint32_t)(mrow[kv] != 0) << (8 * r);
+                }
+        }
+    }
     f32x4 s[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -95,7 +118,7 @@ __device__ __forceinline__ void scores_softmax(const MArgs& a, const char* Qs, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kv = 16 * t + 4 * g + r;
-            const bool ok = kv < a.Skv && !(a.mask && a.mask[(size_t)b * a.Skv + kv]) && !(a.causal && kv > q);
+            const bool ok = kv < a.Skv && ((mw[t] >> (8 * r)) & 0xffu) == 0u && !(a.causal && kv > q);
             s[t][r] = ok ? s[t][r] * a.scale : -INFINITY;
             m = fmaxf(m, s[t][r]);
         }

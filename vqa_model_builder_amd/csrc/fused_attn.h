@@ -80,11 +80,18 @@ __device__ __forceinline__ void fused_store(f32x4 (&acc)[2][TN], char* tile, int
                                             size_t grow0, int gcol0, int lane) {
     constexpr int PITCH = DH * 2 + 16;
     const int g = lane >> 4, li = lane & 15;
+    // every bias vector first: loaded inside the store loop, each load's wait (vmcnt counts stores too) also sat out the previous columns'
+    // global stores -- TN store round trips in a row
+    f32x4 bbs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bbs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias) bbs[j] = *reinterpret_cast<const f32x4*>(bias + gcol0 + c_base + 16 * j + 4 * g);
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int c = c_base + 16 * j + 4 * g;
-        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-        if (bias) bb = *reinterpret_cast<const f32x4*>(bias + gcol0 + c);
+        const f32x4 bb = bbs[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = r_base + 16 * i + li;
