@@ -82,6 +82,7 @@ void vqa_set_gemm_ws(int mode);           /* one-tile-per-CU loader/consumer GEM
 void vqa_set_gemm_grid_cap(int cap);      /* > 0: LDS-DMA GEMMs run persistent on at most `cap` workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_force(int cfg, int stages);   /* diagnostics: tile id (0: 128x128, 1: 64x64, 4: 128x64, 5: 64x128; -1: heuristics) for every LDS-DMA launch */
 void vqa_set_gemm_tile_order(int order);         /* 0 / 1 (default): row-major tile ids; 2: column-major (an XCD owns output columns: every weight line fetched by ONE XCD) -- lab */
+void vqa_set_gemm_k_rotate(int on);             /* 1: workgroups of XCD x start their k loop x/8 of the way through K (one HBM fetch per weight line instead of eight concurrent misses) */
 void vqa_set_gemm_group_persistent(int n); /* > 0: grouped launches run persistent on at most n workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */

@@ -921,3 +921,42 @@ def test_bilinear_as_one_gemm_over_outer_products():
         rx1, rx2, rw = torch.autograd.grad(torch.nn.functional.bilinear(x1r, x2r, wr, b.detach()), [x1r, x2r, wr], dy)
         for g, r in ((gx1, rx1), (gx2, rx2), (gw, rw)):
             assert (g - r).norm() <= 2e-2 * r.norm(), ((g - r).norm() / r.norm()).item()
+
+
+def test_gemm_k_rotation_is_exact_on_integer_data_and_only_reorders_the_sum():
+    """Per-XCD k rotation of the ring GEMMs (csrc/gemm.hip: gemm_v1_body; ON in train() mode, hip/kernels.py: set_training_numerics): the workgroups
+    of XCD x start their k loop x/8 of the way through K and wrap around.  Same products, another fp32 summation order: on integer-valued data
+    (exact in any order) rotated and unrotated launches must agree with the exact product bit for bit -- every layout, ragged M / N / K, split-K,
+    the 32x32 / 64x64 / 128x64 tiles; on real-valued data they differ by fp32 rounding only."""
+    L = hl.load()
+    g = torch.Generator().manual_seed(0)
+
+    def ints(shape):
+        return torch.randint(-3, 4, shape, generator=g).float().to(DEV).to(BF)
+    try:
+        for (M, N, Kd) in [(66, 2304, 768), (32, 2048, 4096), (2048, 768, 3072), (1600, 768, 768), (100, 96, 1000), (136, 136, 520), (2048, 3072, 768)]:
+            for a_kc, b_kc in [(True, True), (True, False), (False, False), (False, True)]:
+                if (not a_kc and M % 8) or (not b_kc and N % 8):
+                    continue                               # a transposed operand needs 16-byte rows (VQA_ERR_ARG otherwise)
+                a = ints((M, Kd) if a_kc else (Kd, M))
+                b = ints((N, Kd) if b_kc else (Kd, N))
+                ref = (a.float() if a_kc else a.float().t()) @ (b.float().t() if b_kc else b.float())
+                for split in (False, True):
+                    for rot in (0, 1):
+                        L.vqa_set_gemm_k_rotate(rot)
+                        o = torch.zeros((M, N), device=DEV)
+                        K.gemm(a, b, M, N, Kd, Kd if a_kc else M, Kd if b_kc else N, a_kc, b_kc, out_f32=o, allow_split_k=split)
+                        assert torch.equal(o, ref), (M, N, Kd, a_kc, b_kc, split, rot)
+        M, N, Kd = 2048, 3072, 768
+        a, w = rnd((M, Kd), 1).to(DEV).to(BF), (rnd((N, Kd), 2) / math.sqrt(Kd)).to(DEV).to(BF)
+        outs = []
+        for rot in (0, 1):
+            L.vqa_set_gemm_k_rotate(rot)
+            o = torch.zeros((M, N), device=DEV)
+            K.gemm(a, w, M, N, Kd, Kd, Kd, True, True, out_f32=o)
+            outs.append(o)
+        err = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
+        assert 0.0 < err < 1e-6, err                       # rotation took place (another summation order) and moved nothing but fp32 rounding
+    finally:
+        L.vqa_set_gemm_k_rotate(0)
+        K._k_rotate_state = None

@@ -65,6 +65,7 @@ struct GemmArgs {
     float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
     int tiles_m_cm; unsigned tiles_m_magic; // > 0: COLUMN-major tile order (tile rows of the launch, and ceil(2^32 / tiles_m)): with the XCD remap every XCD then owns
                                             // a range of output COLUMNS, i.e. every weight line is fetched by ONE XCD (and the activations by all eight)
+    int k_rotate;                           // ring kernels: workgroups on XCD x start their k loop x/8 of the way through K (see gemm_v1_body)
     int epi_dma;                            // epilogue operand staged through LDS by DMA (ring kernels): 0 none, 1 act_grad_of, 2 residual (host: alignment)
 #ifdef VQA_GEMM_TRACE
     unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
@@ -586,10 +587,29 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     DmaLane da[PA], db[PB];
     dma_init<BM, A_KC, BKT, NW>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
     dma_init<BN, B_KC, BKT, NW>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+    // k ROTATION: the workgroups of XCD x (workgroups are dealt round-robin over the XCDs: x = blockIdx.x % 8) walk the k tiles starting x/8 of
+    // the way through K and wrap around.  Every XCD reads the whole weight operand; started together at k = 0 all eight miss on the same lines
+    // at the same time -- in the step the weights always come from HBM (profiles/r02/gemm_cold_weights.log: +2 - 4 us per launch) -- rotated, a
+    // line is fetched from HBM for one XCD and found in the memory-side cache by the other seven.  fp32 accumulation order changes, nothing else.
+    const int rot = (p.k_rotate && nk >= 8) ? (int)(((unsigned)(blockIdx.x & 7) * (unsigned)nk) >> 3) : 0;
+    if (rot) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) da[i].ptr += (unsigned long long)rot * da[i].step;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) db[i].ptr += (unsigned long long)rot * db[i].step;
+    }
     auto issue = [&](int t, int stage) {
         char* st = smem + stage * STAGE_BYTES;
-        if (t < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
-        else { dma_issue<PA, true>(da, st, kbeg + t * BKT, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + t * BKT, wave); }
+        int kk = t + rot;
+        if (kk >= nk) kk -= nk;
+        if (rot && kk == 0) {                                // wrap: this issue is k tile 0
+#pragma unroll
+            for (int i = 0; i < PA; ++i) da[i].ptr -= (unsigned long long)nk * da[i].step;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) db[i].ptr -= (unsigned long long)nk * db[i].step;
+        }
+        if (kk < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
+        else { dma_issue<PA, true>(da, st, kbeg + kk * BKT, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + kk * BKT, wave); }
     };
 #pragma unroll
     for (int t = 0; t < STAGES1 - 1; ++t)
@@ -767,7 +787,7 @@ void gemm_v1_kernel(const GemmArgs p) {
 // one tail for all of them, and thousands of equal-cost tiles balance over the CUs where a single 768 x 768 output has 144.
 constexpr int MAX_GROUP = 32;
 struct GroupItem { const h16_t* a; const h16_t* b; float* c; int M, N, K, lda, ldb, ldc, tiles_n; unsigned tiles_n_magic; };
-struct GroupArgs { int n; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
+struct GroupArgs { int n; int k_rotate; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
@@ -786,6 +806,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const G
         p.c_f32 = it.c; p.ldc_f32 = it.ldc;
         p.alpha = 1.f; p.drop_inv_keep = 1.f; p.tiles_n = it.tiles_n; p.tiles_n_magic = it.tiles_n_magic;
         p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
+        p.k_rotate = g.k_rotate;
         gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
         __syncthreads();                                     // the ring (epilogue scratch) is free again
     }
@@ -1010,6 +1031,12 @@ int g_ws_mode = 0;          // 0: off (default); 1: auto (ws_pick); 2 + i: force
 unsigned g_ws_mask = 0xffffffffu;   // auto mode: bit i allows WS_TILES[i]
 
 int g_force_cfg = -1, g_force_stages = 2;
+int g_k_rotate = 0;        // k rotation per XCD in the ring kernels (vqa_set_gemm_k_rotate; see gemm_v1_body).  The models switch it ON for train()-mode steps
+                           // (hip/kernels.py: set_training_numerics) and OFF otherwise: rotated, a row's fp32 summation order depends on the XCD that
+                           // computes its tile, i.e. a sample's result depends on its batch position at the 16-bit rounding level -- harmless under
+                           // dropout, unwanted for inference and for the bitwise properties the eval-mode tests hold.  One box, cfg2 train step:
+                           // 7.16 -> 6.94 ms, GEMM sum 5.61 -> 5.36 ms; cfg3 9.58 -> 9.32 ms (profiles/r02/gemm_k_rotate.log)
+int g_k_rotate_grouped = 0;  // k rotation in the grouped weight-gradient launch too (vqa_set_gemm_k_rotate(2)): lab
 int g_tile_order = 0;      // 0 / 1: row-major tile ids (default: an XCD owns rows of the output: activations fetched once, weights by every XCD); 2: column-major (lab, see vqa_gemm_bf16)
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
@@ -1171,6 +1198,7 @@ extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
 extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }
 extern "C" void vqa_set_gemm_tile_order(int order) { g_tile_order = order; }
+extern "C" void vqa_set_gemm_k_rotate(int on) { g_k_rotate = on != 0; g_k_rotate_grouped = on >= 2; }
 extern "C" void vqa_set_gemm_pipeline(int v1) {
     // diagnostics for tile_hint launches.  0: register-staged double buffer; 2 / 3: LDS-DMA ring with that many stages
     g_use_v1 = v1 != 0; g_force_dma = v1 != 0;
@@ -1247,6 +1275,9 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
     p.tiles_n = ceil_div(d->N, bn); p.tiles_n_magic = div_magic(p.tiles_n);
     p.tiles_m_cm = 0; p.tiles_m_magic = 0;
+    // only the encoder / fusion GEMMs over all tokens: their weights are what eight XCDs miss on together; the one-token-per-sample launches of the
+    // experts and the head (M <= 128) have one or two tile rows, and their parity margins against the reference are the tightest of the path
+    p.k_rotate = g_k_rotate && d->M >= 256;
     // Column-major tile ids (vqa_set_gemm_tile_order(2)): under the XCD remap every XCD then owns a range of output COLUMNS, so every line of
     // the weight operand is fetched from HBM by one XCD instead of missing in eight L2s at once.  MEASURED, NOT ADOPTED (profiles/r02/gemm_tile_order.log):
     // launch by launch with weights streamed from HBM it wins on every shape (2048x2304x768 19.8 -> 16.1 us, dX 2048x3072x768 21.7 -> 18.3) -- but
@@ -1348,6 +1379,7 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     const int bm = tile == 1 ? 64 : (tile == 4 || tile == 5) ? 256 : 128, bn = (tile == 1 || tile == 2) ? 64 : 128;
     GroupArgs g{};
     g.n = n;
+    g.k_rotate = g_k_rotate_grouped;
     long tiles = 0;
     for (int i = 0; i < n; ++i) {
         const VqaGemmGroupItem& d = items[i];

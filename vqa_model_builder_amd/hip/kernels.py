@@ -100,6 +100,23 @@ def prefetch_weights(tensors, workgroups=64):
     _chk(L().vqa_prefetch(lo, hi - lo, workgroups if PREFETCH_GATED else PREFETCH_WORKGROUPS, ps.cuda_stream), 'vqa_prefetch')
 
 
+# ---- numerics mode of the ring GEMMs ---------------------------------------------------------------------------------------------
+# train(): per-XCD k rotation ON (every weight line fetched from HBM by one XCD instead of missing in eight L2s at once: cfg2 7.16 -> 6.94 ms);
+# a row's fp32 summation order then depends on the XCD that owns its tile.  eval(): OFF -- results are bit-identical whatever the batch position
+# (tests/test_parity_gpu.py::test_full_size_properties_batch32) and the parity fixtures are compared in that mode.  Called by the models' forward.
+TRAIN_K_ROTATE = True
+FORCE_K_ROTATE = False       # tests: rotation on in eval mode too (the eval-mode parity fixtures under train-mode numerics)
+_k_rotate_state = None
+
+
+def set_training_numerics(training: bool):
+    global _k_rotate_state
+    want = 1 if ((training and TRAIN_K_ROTATE) or FORCE_K_ROTATE) else 0
+    if want != _k_rotate_state:
+        L().vqa_set_gemm_k_rotate(want)
+        _k_rotate_state = want
+
+
 _gd = _l.VqaGemmDesc()
 _ad = _l.VqaAttnDesc()
 _fd = _l.VqaFusedAttnDesc()

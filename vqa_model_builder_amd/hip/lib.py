@@ -113,6 +113,7 @@ SIGNATURES = {
     'vqa_set_gemm_grid_cap': (None, [i32]),
     'vqa_set_gemm_force': (None, [i32, i32]),
     'vqa_set_gemm_tile_order': (None, [i32]),
+    'vqa_set_gemm_k_rotate': (None, [i32]),
     'vqa_layernorm_bwd_blocks': (i32, [i32]),
     'vqa_set_layernorm_bwd_blocks': (None, [i32]),
     'vqa_layernorm_bwd_partials': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, u64, u32, i32, vp]),
@@ -177,6 +178,8 @@ def load(path: str = None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype, fn.argtypes = res, args
+    if os.environ.get('VQA_GEMM_K_ROTATE') is not None:       # A/B experiments only (like VQA_HIP_LIB): per-XCD k rotation of the ring GEMMs off / on
+        lib.vqa_set_gemm_k_rotate(int(os.environ['VQA_GEMM_K_ROTATE']))
     if path is None:
         if lib.vqa_half_kind() != (1 if _half == 'fp16' else 0):
             raise HipLibraryMissing(f'{p} was built for the other operand type: rebuild (python -m vqa_model_builder_amd.csrc.build --force)')

@@ -462,6 +462,8 @@ class GenerativeVQAModel(nn.Module):
     def encode_both(self, pixel_values, input_ids, attention_mask):
         """The two encoders; with ``parallel_towers`` set (graph.GraphedTrainStep does) the vision tower runs on a side HIP stream -- its
         backward follows it there -- so the two towers are parallel branches of the captured step (vqa_model.VietnameseVQAModel.encode_both)."""
+        if pixel_values.is_cuda:
+            K.set_training_numerics(self.training)
         if getattr(self, 'parallel_towers', False) and pixel_values.is_cuda:
             main = torch.cuda.current_stream()
             if getattr(self, '_tower_stream', None) is None:

@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from ...hip import kernels as K
 from ...hip import ops
 from ...hip.blocks import CrossModalAttentionRunner, TailRunner
 from ...hip.kernels import ACT_NONE, ACT_RELU, Drop
@@ -435,6 +436,8 @@ class VietnameseVQAModel(nn.Module):
     def encode_both(self, pixel_values, input_ids, attention_mask):
         """(visual_pooled, visual_spatial, text_pooled, text_sequence): the two encoders, on parallel HIP streams when
         ``parallel_towers`` is set."""
+        if pixel_values.is_cuda:
+            K.set_training_numerics(self.training)       # train(): per-XCD k rotation in the ring GEMMs; eval(): batch-position-independent sums
         if getattr(self, 'parallel_towers', False) and pixel_values.is_cuda:
             # The two encoders share nothing until the fusion: run the vision tower on a side HIP stream (its backward
             # follows it there -- autograd replays every node on its forward stream).  A single short GEMM leaves most CUs
