@@ -427,7 +427,7 @@ def main():
         lib.load().vqa_set_gemm_tile_order(args.gemm_tile_order)
     if args.gemm_k_rotate is not None:
         from vqa_model_builder_amd.hip import kernels as _K1
-        _K1.TRAIN_K_ROTATE = bool(args.gemm_k_rotate)
+        _K1.TRAIN_K_ROTATE = args.gemm_k_rotate if args.gemm_k_rotate == 2 else bool(args.gemm_k_rotate)
     if args.gemm_ws is not None:
         lib.load().vqa_set_gemm_ws(args.gemm_ws)
     if args.group_persistent is not None:

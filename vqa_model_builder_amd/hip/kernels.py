@@ -111,7 +111,7 @@ _k_rotate_state = None
 
 def set_training_numerics(training: bool):
     global _k_rotate_state
-    want = 1 if ((training and TRAIN_K_ROTATE) or FORCE_K_ROTATE) else 0
+    want = (2 if TRAIN_K_ROTATE == 2 else 1) if ((training and TRAIN_K_ROTATE) or FORCE_K_ROTATE) else 0       # 2 (lab): the grouped weight-gradient launch too
     if want != _k_rotate_state:
         L().vqa_set_gemm_k_rotate(want)
         _k_rotate_state = want
