@@ -21,17 +21,28 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = cols / 4;
     for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
-        f32x4 v[NV];
+        // Every global load of the row is issued up front, UNCONDITIONALLY (lanes past the row end read a clamped chunk and discard it): behind
+        // per-chunk `if (c < c4)` branches the compiler waited for each chunk before loading the next -- NV dependent round trips per row, and
+        // a second chain for gamma / beta between the stores (ISA of round 2: G G [vmcnt(0)] x NV ... S S G G [vmcnt(0)] x NV)
+        f32x4 v[NV], av[NV], gv[NV], bv[NV];
         float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[min(lane + 64 * i, c4 - 1)];
+        if (add) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) av[i] = reinterpret_cast<const f32x4*>(add + (size_t)row * cols)[min(lane + 64 * i, c4 - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            gv[i] = reinterpret_cast<const f32x4*>(gamma)[min(lane + 64 * i, c4 - 1)];
+            bv[i] = reinterpret_cast<const f32x4*>(beta)[min(lane + 64 * i, c4 - 1)];
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c < c4) {
-                v[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[c];
-                if (add) v[i] += reinterpret_cast<const f32x4*>(add + (size_t)row * cols)[c];
-                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-            }
+            if (add) v[i] += av[i];
+            if (c < c4) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         const float mean = wave_sum(s) / cols;
         float q = 0.f;
@@ -49,8 +60,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_fwd_kernel(
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             if (c < c4) {
-                const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c];
-                const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c];
+                const f32x4 g = gv[i], b = bv[i];
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
@@ -78,22 +88,32 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
     f32x4 dg[NV], db[NV], g[NV], cs[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; g[i] = dg[i]; cs[i] = dg[i];
-        const int c = lane + 64 * i;
-        if (c < c4) g[i] = reinterpret_cast<const f32x4*>(gamma)[c];
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; cs[i] = dg[i];
+        g[i] = reinterpret_cast<const f32x4*>(gamma)[min(lane + 64 * i, c4 - 1)];        // unconditional (clamped): one batch of loads, see below
     }
     for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
         const float mean = mean_in[row], rstd = rstd_in[row];
         f32x4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
+        // all global loads of the row up front and unconditional (clamped chunk for lanes past the row end; never used): per-chunk branches made
+        // every chunk its own dependent round trip, and the residual-gradient loads between the stores waited for those stores too
+        f32x4 dv[NV], xv_[NV], rv_[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dv[i] = reinterpret_cast<const f32x4*>(dy + (size_t)row * cols)[min(lane + 64 * i, c4 - 1)];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) xv_[i] = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[min(lane + 64 * i, c4 - 1)];
+        if (dres) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) rv_[i] = reinterpret_cast<const f32x4*>(dres + (size_t)row * cols)[min(lane + 64 * i, c4 - 1)];
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
             xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; gy[i] = xh[i];
             if (c < c4) {
-                f32x4 d = reinterpret_cast<const f32x4*>(dy + (size_t)row * cols)[c];
+                f32x4 d = dv[i];
                 if (drop_mode == 2) d *= dropout_scale4(seed, stream, (uint64_t)row * cols + 4 * c, drop_p, inv_keep);
-                const f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)row * cols)[c];
+                const f32x4 xv = xv_[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     xh[i][j] = (xv[j] - mean) * rstd;
@@ -114,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[i][j] - s1 - xh[i][j] * s2);
-                if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * cols)[c];
+                if (dres) o += rv_[i];
                 if (dx) reinterpret_cast<f32x4*>(dx + (size_t)row * cols)[c] = o;
                 if (dxb || want_colsum) {
                     h16x4 ob;
