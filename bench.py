@@ -373,6 +373,7 @@ def main():
                     help="how the data-parallel captured step cuts the encoders' backward: 'depth' = up to four depth segments, text and vision layers of a segment as "
                          "parallel branches of one graph (default); 'towers' = text backward then vision backward, each in two graphs")
     ap.add_argument('--no-wire-optimizer', action='store_true', help='diagnostics: copy the all-reduced bf16 sums back into the fp32 gradient arenas before the optimiser (first form of round 2)')
+    ap.add_argument('--ln-bwd-blocks', type=int, default=None, help='diagnostics: vqa_set_layernorm_bwd_blocks (workgroups of the LayerNorm backward kernel)')
     ap.add_argument('--gemm-k-rotate', type=int, default=None, help='diagnostics: 0 = no per-XCD k rotation of the ring GEMMs in train() mode (kernels.TRAIN_K_ROTATE; default: on in train mode, off in eval)')
     ap.add_argument('--gemm-tile-order', type=int, default=None, help='diagnostics: vqa_set_gemm_tile_order (2 = column-major tile ids: measured slower in the step)')
     ap.add_argument('--prefetch-wgs', type=int, default=None, help='diagnostics: workgroups of a self-paced weight-prefetch kernel (kernels.PREFETCH_WORKGROUPS); -1 = event-gated prefetch')
@@ -423,6 +424,8 @@ def main():
         if args.prefetch_wgs is not None:
             _K0.PREFETCH_GATED = args.prefetch_wgs < 0
             _K0.PREFETCH_WORKGROUPS = max(1, args.prefetch_wgs)
+    if args.ln_bwd_blocks is not None:
+        lib.load().vqa_set_layernorm_bwd_blocks(args.ln_bwd_blocks)
     if args.gemm_tile_order is not None:
         lib.load().vqa_set_gemm_tile_order(args.gemm_tile_order)
     if args.gemm_k_rotate is not None:
