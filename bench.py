@@ -252,8 +252,8 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
             eager_step()
         torch.cuda.synchronize()
         import ctypes as C
-        flop, msec, cnt = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int * 2)()
-        L.vqa_gemm_profile_collect(2, flop, msec, cnt)
+        flop, msec, cnt, byt = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int * 2)(), (C.c_double * 2)()
+        L.vqa_gemm_profile_collect2(2, flop, msec, cnt, byt)
         L.vqa_gemm_profile(0, 0)
         for h in hooks:
             h.remove()
@@ -262,6 +262,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         ach = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         fus = fus_flop / (fus_ms * 1e-3) / 1e12 if fus_ms > 0 else None
         res['gemm'] = {'flop_per_step': tot_flop, 'ms_per_step': tot_ms, 'launches_per_step': launches, 'tflops': ach,
+                       'alg_bytes_per_step': (byt[0] + byt[1]) / n_prof,
                        'fusion_flop_per_step': fus_flop, 'fusion_ms_per_step': fus_ms, 'fusion_tflops': fus}
     # free the workload (the next one builds its own model / graph pools)
     del step, eager_step
@@ -461,7 +462,7 @@ def main():
         # rocprofv3 on this same command (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) by
         # profiles/pmc_traffic.py and committed with their raw counter CSVs
         traffic, traffic_src = None, None
-        for rnd in ('r02', 'r01'):
+        for rnd in ('r03', 'r02', 'r01'):
             try:
                 tj = json.load(open(os.path.join(REPO, 'profiles', rnd, 'gemm_traffic.json')))
                 if args.workload == 'cfg2_xattn' and args.batch == 32:
@@ -473,23 +474,36 @@ def main():
         ms = main_res['ms_per_step']
         # the same quantity from the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/collect.sh): the live bracket
         # (hipExtLaunchKernel start / stop events) runs ~12 % longer than rocprof's per-dispatch durations -- the start stamp is taken at
-        # dispatch, ~2.8 us before the kernel's first wave on a dependent chain -- so the live `frac` is the conservative one
+        # dispatch, ~2.8 us before the kernel's first wave on a dependent chain -- so the live `frac` is the conservative one.
+        # Numerator and denominator cover the SAME launches: every row of the MFMA GEMM family the live bracket counts FLOPs for
+        # (gemm_v1* / gemm_kernel / gemm_ws ring and register-staged GEMMs, the grouped launches, the fused in-projection + attention
+        # and cross-attention block kernels) -- recomputable by hand from the committed CSV.
         rocprof = None
-        try:
-            import csv
-            rows = list(csv.DictReader(open(os.path.join(REPO, 'profiles', 'r02', 'eager_kernel_stats.csv'))))
-            nsteps = sum(int(r['Calls']) for r in rows if 'adamw_multi_kernel' in r['Name']) / 2.0
-            gms = sum(int(r['TotalDurationNs']) for r in rows if 'gemm_v1' in r['Name']) / 1e6 / nsteps
-            if args.workload == 'cfg2_xattn' and args.batch == 32 and gms > 0:
-                rocprof = {'gemm_ms_per_step': round(gms, 3), 'tflops': round(g['flop_per_step'] / (gms * 1e-3) / 1e12, 1),
-                           'frac': round(g['flop_per_step'] / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                           'source': 'profiles/r02/eager_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --eager, committed; not measured in this run)'}
-        except Exception:
-            rocprof = None
+        FAMILY = ('gemm_v1', 'gemm_kernel', 'gemm_ws', 'gemm_grp', 'fused_inproj_attn_kernel', 'xattn_block')
+        for rnd in ('r03', 'r02'):
+            try:
+                import csv
+                path = os.path.join(REPO, 'profiles', rnd, 'eager_kernel_stats.csv')
+                rows = list(csv.DictReader(open(path)))
+                nsteps = sum(int(r['Calls']) for r in rows if 'adamw_multi_kernel' in r['Name']) / 2.0
+                fam = [r for r in rows if any(f in r['Name'] for f in FAMILY)]
+                gms = sum(int(r['TotalDurationNs']) for r in fam) / 1e6 / nsteps
+                if args.workload == 'cfg2_xattn' and args.batch == 32 and gms > 0:
+                    rocprof = {'gemm_ms_per_step': round(gms, 3), 'tflops': round(g['flop_per_step'] / (gms * 1e-3) / 1e12, 1),
+                               'frac': round(g['flop_per_step'] / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               'launches_per_step': round(sum(int(r['Calls']) for r in fam) / nsteps, 1), 'profiled_steps': nsteps,
+                               'rows': 'Name contains one of ' + ' | '.join(FAMILY),
+                               'source': f'profiles/{rnd}/eager_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --eager, committed; not measured in this run): '
+                                         'frac = flop_per_step of this run / (sum of TotalDurationNs of those rows / profiled_steps) / peak'}
+                break
+            except Exception:
+                rocprof = None
         roofline = {'bound': 'mfma', 'kernel': 'gemm_v1_kernel / gemm_v1_grouped_kernel (all MFMA GEMM launches of a step)',
                     'achieved': round(g['tflops'], 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(g['tflops'] / PEAK_BF16_TFLOPS, 4),
                     'timing': 'kernel begin/end timestamps of every GEMM dispatch (hipExtLaunchKernel start/stop events) = what rocprofv3 --kernel-trace reports',
                     'traffic': traffic, 'traffic_unit': 'B/launch (HBM side)', 'traffic_source': traffic_src,
+                    # what the launches must move at least: both operands once + every output / fused epilogue stream once, per launch like `traffic`
+                    'algorithmic_bytes': round(g['alg_bytes_per_step'] / max(1, g['launches_per_step'])), 'algorithmic_bytes_per_step': round(g['alg_bytes_per_step']),
                     'launches_per_step': g['launches_per_step'], 'gemm_ms_per_step': round(g['ms_per_step'], 3),
                     'gemm_gflop_per_step': round(g['flop_per_step'] / 1e9, 1),
                     'fusion_gemm_tflops': None if g['fusion_tflops'] is None else round(g['fusion_tflops'], 2),

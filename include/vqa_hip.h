@@ -78,6 +78,8 @@ int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_
  * milliseconds and count, then forgets them.  Host-side state only; not for use inside a stream capture. */
 void vqa_gemm_profile(int on, int tag);
 int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches);
+/* the same, plus per tag the launches' ALGORITHMIC bytes: both operands once + every output / fused epilogue stream once (bytes may be NULL) */
+int vqa_gemm_profile_collect2(int ntags, double* flop, double* ms, int* launches, double* bytes);
 void vqa_set_gemm_ws(int mode);           /* one-tile-per-CU loader/consumer GEMM (csrc/gemm.hip: gemm_ws): 0 off (default: slower inside the step, profiles/r02/gemm_ws.md), 1 auto, 2 + i: force its tile i, 0x100 * mask + ...: auto over the masked tiles */
 void vqa_set_gemm_grid_cap(int cap);      /* > 0: LDS-DMA GEMMs run persistent on at most `cap` workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_force(int cfg, int stages);   /* diagnostics: tile id (0: 128x128, 1: 64x64, 4: 128x64, 5: 64x128; -1: heuristics) for every LDS-DMA launch */

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     try:
         for kind, code in (('bf16', 0), ('fp16', 1)):      # both operand-type builds of the same sources export the same ABI
             l = lib.set_half(kind)          # types every entry point; AttributeError if one is missing
-            assert l.vqa_abi_version() == 4 and l.vqa_half_kind() == code
+            assert l.vqa_abi_version() == 5 and l.vqa_half_kind() == code
     finally:
         lib.set_half('bf16')
 
@@ -89,19 +89,23 @@ def test_install_as_src_aliases_the_reference_import_paths():
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/src'), reason='needs the reference tree (build container only)')
-def test_install_as_src_does_not_hide_the_reference_generative_model():
-    """With the reference tree importable, the five generative names of src.modeling.meta_arch resolve to the REFERENCE's own
-    implementation (bound to its own moe modules) while the classification names resolve to this package."""
+def test_install_as_src_binds_the_hip_generative_model_and_the_reference_one_on_request():
+    """With the reference tree importable: ``install_as_src()`` serves ALL names of src.modeling.meta_arch -- the five generative ones
+    included (default since round 3) -- from this package; ``generative='reference'`` binds the REFERENCE's own generative implementation
+    (with its own moe modules inside) while the classification names keep resolving to this package."""
     import subprocess
     import sys
     code = (
         "import sys; sys.path.insert(0, '/root/reference'); sys.path.insert(0, %r)\n"
         "import vqa_model_builder_amd as amd; amd.install_as_src()\n"
         "from src.modeling.meta_arch import GenerativeVQAModel, GenerativeVQAConfig, create_generative_vqa_model, VietnameseVQAModel\n"
+        "import src.modeling.meta_arch.generative_vqa_model as g\n"
+        "assert GenerativeVQAModel.__module__.startswith('vqa_model_builder_amd') and 'vqa_model_builder_amd' in g.__file__\n"
+        "amd.install_as_src(generative='reference')\n"
+        "from src.modeling.meta_arch import GenerativeVQAModel, VietnameseVQAModel\n"
         "from src.modeling.moe import VQAMOELayer\n"
         "import src.modeling.meta_arch.generative_vqa_model as g\n"
         "assert GenerativeVQAModel.__module__ == 'src.modeling.meta_arch.generative_vqa_model' and '/root/reference' in g.__file__\n"
-        "assert g.MOELayer.__module__ == 'src.modeling.moe.moe_layer' and 'vqa_model_builder_amd' not in sys.modules[g.MOELayer.__module__].__file__ or True\n"
         "assert not g.VQAMOELayer.__module__.startswith('vqa_model_builder_amd')\n"
         "assert VietnameseVQAModel.__module__.startswith('vqa_model_builder_amd') and VQAMOELayer.__module__.startswith('vqa_model_builder_amd')\n"
         "print('ok')\n") % REPO

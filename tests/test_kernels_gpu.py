@@ -870,6 +870,66 @@ def test_fused_adamw_loss_scale_skips_non_finite_steps_like_gradscaler():
     assert opt.loss_scale == scaler.get_scale()
 
 
+def test_fused_adamw_follows_a_warmup_schedule_and_keeps_per_parameter_steps_in_amp_mode():
+    """The reference loop's exact regime (training_pipeline.py:311-318,346-347,466-512): fp16 GradScaler + a LambdaLR warm-up whose first
+    factor is 0 + ``scheduler.step()`` after every optimiser step.  With ``loss_scale`` set the step count (and the learning rate) live in device
+    words from the first step on; the learning rate must follow ``group['lr']`` WITHOUT the caller refreshing anything (round-2 advisor finding:
+    it froze at the first step's value, i.e. at 0), a parameter whose first gradient arrives later starts its OWN bias corrections (torch keeps
+    ``step`` per parameter), a skipped step counts for nobody, and ``state_dict()`` reports those per-parameter counts."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    torch.manual_seed(5)
+    shapes = [(40, 24), (130,), (16, 8)]
+    base = [torch.randn(s, device=DEV) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone()) for t in base]
+    ref = [torch.nn.Parameter(t.clone()) for t in base]
+    groups = lambda ps: [{'params': ps[:1], 'weight_decay': 0.01}, {'params': ps[1:], 'weight_decay': 0.0}]
+    opt = FusedAdamW(groups(mine), lr=1e-2, max_grad_norm=1.0, loss_scale='dynamic', growth_interval=4)
+    o_ref = torch.optim.AdamW(groups(ref), lr=1e-2)
+    lam = lambda s: min(1.0, s / 4.0)                             # lr_lambda(0) = 0, as the reference's warm-up
+    sch, sch_ref = torch.optim.lr_scheduler.LambdaLR(opt, lam), torch.optim.lr_scheduler.LambdaLR(o_ref, lam)
+    scaler = torch.amp.GradScaler('cuda', init_scale=65536.0, growth_interval=4)
+    scaler.scale(torch.zeros(1, device=DEV))
+    late = 2                                                      # parameter 2 (an expert nobody routed to yet) gets no gradient before step 3
+    for step in range(10):
+        gs = [torch.randn(s, device=DEV) * (3.0 if step % 2 else 0.1) for s in shapes]
+        if step == 5:
+            gs[1][7] = float('nan')
+        s_mine, s_ref = opt.loss_scale, scaler.get_scale()
+        assert s_mine == s_ref, (step, s_mine, s_ref)
+        for i, (p, q, g) in enumerate(zip(mine, ref, gs)):
+            if i == late and step < 3:
+                p.grad = q.grad = None
+                continue
+            p.grad, q.grad = g * s_mine, g.clone() * s_ref
+        opt.step()
+        scaler.unscale_(o_ref)
+        torch.nn.utils.clip_grad_norm_([q for q in ref if q.grad is not None], 1.0)
+        scaler.step(o_ref)
+        scaler.update()
+        sch.step(); sch_ref.step()
+        assert opt.param_groups[0]['lr'] == o_ref.param_groups[0]['lr']
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), (a - b).abs().max()
+    assert not torch.equal(mine[0].detach(), base[0])             # the model did train (the frozen-lr bug left it where it started)
+    sd = opt.state_dict()['state']
+    assert [int(sd[i]['step']) for i in range(3)] == [int(o_ref.state[q]['step']) for q in ref] == [9, 9, 6]
+    # resuming: an optimiser that loads these heterogeneous counts goes device-side again without complaint and continues like torch
+    opt2 = FusedAdamW(groups(mine), lr=1e-2, max_grad_norm=1.0)
+    opt2.load_state_dict(opt.state_dict())
+    opt2.make_capturable(DEV)
+    o_ref.param_groups[0]['lr'] = o_ref.param_groups[1]['lr'] = opt2.param_groups[0]['lr'] = opt2.param_groups[1]['lr'] = 3e-3
+    gs = [torch.randn(s, device=DEV) * 0.1 for s in shapes]
+    for p, q, g in zip(mine, ref, gs):
+        p.grad, q.grad = g.clone(), g.clone()
+    opt2.step()
+    torch.nn.utils.clip_grad_norm_(ref, 1.0)
+    o_ref.step()
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), (a - b).abs().max()
+    opt2.sync_step_counts()
+    assert [int(opt2.state[p]['step']) for p in mine] == [10, 10, 7]
+
+
 def test_fp16_library_gemm_layouts_exact_and_library_switch():
     """The fp16 build (libvqa_hip_f16.so, v_mfma_f32_16x16x32_f16): same layouts, exact on integer data; the operand type is a
     process-wide switch and both handles stay usable."""

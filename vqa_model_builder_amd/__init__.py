@@ -9,7 +9,7 @@ import importlib
 import sys
 import types
 
-__version__ = '0.2.0'
+__version__ = '0.3.0'
 
 
 def set_compute_dtype(kind: str = 'bf16'):
@@ -46,8 +46,8 @@ _GENERATIVE = ('GenerativeVQAConfig', 'GenerativeVQAOutput', 'GenerativeVQAModel
 
 def _reference_generative():
     """The reference's OWN ``src/modeling/meta_arch/generative_vqa_model.py`` when the reference tree is importable (its ``src``
-    package is on sys.path), loaded with the reference's own ``src.modeling.moe`` modules bound inside it -- the HIP generative
-    model is a first build, so ``install_as_src`` does not hide the reference's by default.  None otherwise."""
+    package is on sys.path), loaded with the reference's own ``src.modeling.moe`` modules bound inside it: what
+    ``install_as_src(generative='reference')`` binds on request.  None otherwise."""
     import importlib.util
     import os
     src = sys.modules.get('src')
@@ -74,7 +74,7 @@ def _reference_generative():
     return mod
 
 
-def install_as_src(force: bool = False, generative: str = 'reference'):
+def install_as_src(force: bool = False, generative: str = 'hip'):
     """Registers this package's modules under the dotted names the reference imports them by
     (``from src.modeling.meta_arch import ...`` model_pipeline.py:189-197,307; ``from src.modeling.moe import VQAMOELayer``
     vqa_model.py:529; ``from src.modeling.moe.router import create_router`` ablation_trainer.py:205).  Parent packages
@@ -95,10 +95,10 @@ def install_as_src(force: bool = False, generative: str = 'reference'):
             parent, _, leaf = alias.rpartition('.')
             if parent in sys.modules:
                 setattr(sys.modules[parent], leaf, mod)
-    # the five generative names of src.modeling.meta_arch (meta_arch/__init__.py:39-71).  generative='reference' (default): the
-    # reference's own implementation when its tree is importable -- the HIP generative model is a first, untuned build and does not
-    # cover moe_type='sparse', so it must be asked for: generative='hip' binds vqa_model_builder_amd's (also the fallback when the
-    # reference tree is absent).
+    # the five generative names of src.modeling.meta_arch (meta_arch/__init__.py:39-71).  generative='hip' (default since round 3): this
+    # package's GenerativeVQAModel -- pinned against reference-run fixtures at full size (330 M parameters, 64 000-way head) in both
+    # operand types, with use_moe (moe_type 'vqa' / 'standard' / 'sparse') covered (tests/test_generative_gpu.py).
+    # generative='reference' keeps the reference's own implementation when its tree is importable (falls back to 'hip' when it is not).
     gen = _reference_generative() if generative == 'reference' else None
     if gen is None:
         gen = importlib.import_module('vqa_model_builder_amd.modeling.meta_arch.generative_vqa_model')

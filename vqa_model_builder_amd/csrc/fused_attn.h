@@ -183,6 +183,9 @@ int launch_fused_attn(const FusedArgs& p, hipStream_t st) {
         attr_set = true;
     }
     const double flop = 2.0 * p.a.B * ((double)p.a.Sq * p.D * p.D + 2.0 * p.a.Skv * p.D * p.D) + 4.0 * p.a.B * p.a.H * (double)p.a.Sq * p.a.Skv * DH;
-    vqa_launch(kern, dim3(p.a.B * p.a.H), dim3(512), LDS, st, p, flop);
+    const double rows_q = (double)p.a.B * p.a.Sq, rows_kv = (double)p.a.B * p.a.Skv;
+    const double bytes = 2.0 * (rows_q + (p.xkv != p.xq ? rows_kv : 0.0)) * p.D + 2.0 * 3.0 * p.D * p.D + (p.bias ? 12.0 * p.D : 0.0) +
+                         2.0 * p.D * ((p.q ? rows_q : 0.0) + (p.k ? rows_kv : 0.0) + (p.v ? rows_kv : 0.0)) + 2.0 * rows_q * p.D;
+    vqa_launch(kern, dim3(p.a.B * p.a.H), dim3(512), LDS, st, p, flop, bytes);
     return (int)hipGetLastError();
 }

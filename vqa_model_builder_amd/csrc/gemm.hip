@@ -29,7 +29,7 @@ namespace {
 // the events receive the kernel's own begin / end timestamps from its dispatch packet -- the quantity rocprofv3
 // --kernel-trace reports -- so bench.py's roofline numbers are rocprof-equivalent without a profiler attached (an ordinary
 // hipEventRecord bracket adds ~3 us of host / queue latency per launch).  Off (default): a plain launch, nothing recorded.
-struct ProfRec { hipEvent_t a, b; double flop; int tag; };
+struct ProfRec { hipEvent_t a, b; double flop, bytes; int tag; };      // bytes: ALGORITHMIC bytes of the launch (operands once + every output / epilogue stream once)
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;      // events created when profiling is switched on, not per launch: two hipEventCreate calls per launch left the
                                           // GPU idle between kernels, and the same kernels then measured ~12 % longer than under rocprofv3 (5.5 vs 4.8 ms of
@@ -38,9 +38,9 @@ bool g_prof_on = false;
 int g_prof_tag = 0;
 
 template <class Kern, class Arg>
-inline void vqa_launch(Kern kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const Arg& arg, double flop) {
+inline void vqa_launch(Kern kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, const Arg& arg, double flop, double bytes = 0.0) {
     if (!g_prof_on) { hipLaunchKernelGGL(kern, grid, block, lds, st, arg); return; }
-    ProfRec r{nullptr, nullptr, flop, g_prof_tag};
+    ProfRec r{nullptr, nullptr, flop, bytes, g_prof_tag};
     if (g_prof_pool.size() >= 2) { r.a = g_prof_pool.back(); g_prof_pool.pop_back(); r.b = g_prof_pool.back(); g_prof_pool.pop_back(); }
     else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { hipLaunchKernelGGL(kern, grid, block, lds, st, arg); return; }
     hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)lds, st, r.a, r.b, 0, arg);
@@ -75,6 +75,12 @@ struct GemmArgs {
     unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
 #endif
 };
+// algorithmic bytes of one launch: both operands read once, every output / fused epilogue stream once (what roofline.algorithmic_bytes sums)
+static inline double gemm_alg_bytes(const GemmArgs& p) {
+    const double mn = (double)p.M * p.N;
+    return 2.0 * ((double)p.M * p.K + (double)p.N * p.K) + (p.c_f32 ? 4.0 * mn : 0.0) + (p.c_bf16 ? 2.0 * mn : 0.0) + (p.pre_bf16 ? 2.0 * mn : 0.0) +
+           (p.residual ? 4.0 * mn : 0.0) + (p.act_grad_of ? 2.0 * mn : 0.0) + (p.bias ? 4.0 * p.N : 0.0) + (p.colsum ? 4.0 * p.N : 0.0);
+}
 #ifdef VQA_GEMM_TRACE
 #define VQA_T(i) do { if (wave == 0) tr[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -1061,7 +1067,7 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int grid = tiles;
     if (g_grid_cap > 0 && splits == 1 && tiles > g_grid_cap) grid = g_grid_cap / 8 * 8;
-    vqa_launch(kern, dim3(grid, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p, 2.0 * p.M * p.N * p.K);
+    vqa_launch(kern, dim3(grid, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p, 2.0 * p.M * p.N * p.K, gemm_alg_bytes(p));
     return (int)hipGetLastError();
 }
 template <int BM, int BN, int WM_, int WN_, int BKT, int ST>
@@ -1100,7 +1106,7 @@ int launch_wsk(const GemmArgs& p, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    vqa_launch(kern, dim3(tiles), dim3(512), LDS, st, p, 2.0 * p.M * p.N * p.K);
+    vqa_launch(kern, dim3(tiles), dim3(512), LDS, st, p, 2.0 * p.M * p.N * p.K, gemm_alg_bytes(p));
     return (int)hipGetLastError();
 }
 template <int BM, int BN, int ST>
@@ -1148,7 +1154,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& p, int a_kc, int b_kc, int splits, hipStream_t st) {
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     dim3 grid(tiles, 1, splits), block(NTHREADS);
-#define VQA_LAUNCH(AK, BKC, TR) vqa_launch(gemm_kernel<BM, BN, WM, WN, AK, BKC, TR>, grid, block, 0, st, p, 2.0 * p.M * p.N * p.K)
+#define VQA_LAUNCH(AK, BKC, TR) vqa_launch(gemm_kernel<BM, BN, WM, WN, AK, BKC, TR>, grid, block, 0, st, p, 2.0 * p.M * p.N * p.K, gemm_alg_bytes(p))
     if (a_kc && b_kc) VQA_LAUNCH(true, true, true);
     else if (a_kc && !b_kc) { if (g_use_tr) VQA_LAUNCH(true, false, true); else VQA_LAUNCH(true, false, false); }
     else if (!a_kc && !b_kc) { if (g_use_tr) VQA_LAUNCH(false, false, true); else VQA_LAUNCH(false, false, false); }
@@ -1188,20 +1194,21 @@ extern "C" void vqa_gemm_profile(int on, int tag) {
         while (g_prof_pool.size() < 4096) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; g_prof_pool.push_back(e); }
     }
 }
-extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches) {
-    for (int t = 0; t < ntags; ++t) { flop[t] = 0.0; ms[t] = 0.0; launches[t] = 0; }
+extern "C" int vqa_gemm_profile_collect2(int ntags, double* flop, double* ms, int* launches, double* bytes) {
+    for (int t = 0; t < ntags; ++t) { flop[t] = 0.0; ms[t] = 0.0; launches[t] = 0; if (bytes) bytes[t] = 0.0; }
     int rc = 0;
     for (ProfRec& r : g_prof) {
         float e = 0.f;
         hipError_t err = hipEventSynchronize(r.b);
         if (err == hipSuccess) err = hipEventElapsedTime(&e, r.a, r.b);
         if (err != hipSuccess) rc = (int)err;
-        else if (r.tag >= 0 && r.tag < ntags) { flop[r.tag] += r.flop; ms[r.tag] += e; launches[r.tag] += 1; }
+        else if (r.tag >= 0 && r.tag < ntags) { flop[r.tag] += r.flop; ms[r.tag] += e; launches[r.tag] += 1; if (bytes) bytes[r.tag] += r.bytes; }
         g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b);        // back into the pool
     }
     g_prof.clear();
     return rc;
 }
+extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches) { return vqa_gemm_profile_collect2(ntags, flop, ms, launches, nullptr); }
 extern "C" void vqa_set_gemm_ws(int mode) { if (mode >= 0x100) { g_ws_mode = 1; g_ws_mask = (unsigned)(mode >> 8); } else { g_ws_mode = mode; g_ws_mask = 0xffffffffu; } }
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
@@ -1352,11 +1359,14 @@ static int launch_grouped(const GroupArgs& g, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    double flop = 0.0;
-    for (int i = 0; i < g.n; ++i) flop += 2.0 * g.it[i].M * g.it[i].N * g.it[i].K;
+    double flop = 0.0, bytes = 0.0;
+    for (int i = 0; i < g.n; ++i) {
+        flop += 2.0 * g.it[i].M * g.it[i].N * g.it[i].K;
+        bytes += 2.0 * ((double)g.it[i].M + g.it[i].N) * g.it[i].K + 4.0 * (double)g.it[i].M * g.it[i].N;
+    }
     int grid = g.tile_end[g.n - 1];
     if (g_group_persistent > 0 && grid > g_group_persistent) grid = g_group_persistent / 8 * 8;      // a multiple of 8: the XCD remap stays a bijection
-    vqa_launch(kern, dim3(grid), dim3(WM_ * WN_ * 64), LDS, st, g, flop);
+    vqa_launch(kern, dim3(grid), dim3(WM_ * WN_ * 64), LDS, st, g, flop, bytes);
     return (int)hipGetLastError();
 }
 

@@ -44,12 +44,18 @@ class DevicePrefetcher:
             raise RuntimeError('DevicePrefetcher feeds a GPU; there is no CPU path on the product side')
         self.stream = torch.cuda.Stream(self.device)
         self._pinned = [{}, {}]
+        self._slot_events = [None, None]               # per pinned slot: the event behind the last H2D copy that READ its buffers
         self._slot = 0
 
     def _stage(self, batch):
-        pin = self._pinned[self._slot]
+        slot = self._slot
+        pin = self._pinned[slot]
         self._slot ^= 1
         out = dict(batch)
+        if self.pin and self._slot_events[slot] is not None:
+            # the non-blocking copy issued from this slot two batches ago may still be reading it if the side stream lags: the host
+            # rewrite below must wait for it on the HOST (the consumer stream's wait_event orders device work only)
+            self._slot_events[slot].synchronize()
         with torch.cuda.stream(self.stream):
             for k in self.keys:
                 t = batch.get(k)
@@ -64,6 +70,7 @@ class DevicePrefetcher:
                 out[k] = t.to(self.device, non_blocking=True)            # -> HBM on the side stream
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._slot_events[slot] = ev
         return out, ev
 
     def __iter__(self) -> Iterator[Dict[str, Any]]:
@@ -75,7 +82,7 @@ class DevicePrefetcher:
         while nxt is not None:
             cur, ev = nxt
             try:
-                # the slot about to be overwritten belonged to the batch handed out one iteration ago: its copy has long finished
+                # the pinned slot about to be rewritten belonged to the batch handed out one iteration ago (_stage waits for its copy)
                 nxt = self._stage(next(it))
             except StopIteration:
                 nxt = None

@@ -408,7 +408,7 @@ class GradReducer:
 
     def segment_gather_bytes(self) -> Dict[str, int]:
         """Bytes each rank contributes to a segment's all-gathers (sparse embedding rows); included world-fold in segment_bytes()."""
-        return {k: s.get('gather_bytes_per_rank', 0) for k, s in getattr(self, '_segments', {}).items()}
+        return {k: s.get('gather_bytes_per_rank', 0) for k, s in (self._segments or {}).items()}
 
     def segment_bytes(self) -> Dict[str, int]:
         return {k: v['bytes'] for k, v in (self._segments or {}).items()}

@@ -168,6 +168,7 @@ class GraphedTrainStep:
             enc = getattr(getattr(model, 'text_encoder', None), 'encoder', None)
             if sparse_embeddings and hasattr(enc, 'sparse_grad_rows'):
                 sparse.append(enc.sparse_grad_rows)           # the word table travels as (ids, rows), not as a 196-MB dense gradient
+            self._check_split_gradients_alias_their_arena()
             reducer.prepare_static(seg_of, order, sparse=sparse)
             # the device-side packing of each segment (stand-alone gradients -> pack buffer, bf16 wire copies) is a small graph of
             # its own, replayed right behind the segment's backward graph
@@ -184,6 +185,21 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_opt, pool=pool, **kw):
                 self.opt.step()
             self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def _check_split_gradients_alias_their_arena(self):
+        """A block whose backward is cut over several graphs hands autograd views of its gradient arena BEFORE the lower layers' slots are
+        written (a later graph fills them).  That is correct only if ``p.grad`` is that very view; had AccumulateGrad cloned one (a
+        layout-contract or refcount miss, a non-contiguous parameter), ``p.grad`` would be private storage holding not-yet-computed
+        data and the exchange would pack garbage every step, silently.  Checked once, after the capture."""
+        blocks = list(self._depth['blocks'].values()) if self._depth is not None else [b for b, _ in self._splits.values()]
+        for blk in blocks:
+            arena = getattr(blk, '_split_arena_ptr', None)
+            if arena is None:
+                continue
+            for key, p in blk._flat:
+                if p.requires_grad and p.grad is not None and p.grad.untyped_storage().data_ptr() != arena:
+                    raise RuntimeError(f'segmented step: the gradient of {type(blk).__name__} parameter {key!r} does not alias the block\'s gradient arena '
+                                       '(autograd copied the view it was handed): its lower-layer slots would never reach p.grad')
 
     # ---- single-graph step -----------------------------------------------------------------------------------------------
     def _backward(self, loss):
@@ -366,6 +382,8 @@ class GraphedTrainStep:
         if batch is not None:
             for k, v in batch.items():
                 self.static[k].copy_(v, non_blocking=True)
+        if hasattr(self.opt, 'refresh_lr'):
+            self.opt.refresh_lr()                        # a scheduler moved group['lr'] since the last replay: one small fill per changed step class
         timed = self.segmented and len(self._exposed_ms) < 512
         order = self._order
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 2)] if timed else None
@@ -420,4 +438,4 @@ class GraphedTrainStep:
         for m in self.model.modules():
             a = getattr(m, '_active', None)
             if a is not None and getattr(m, 'dense_dispatch', False):
-                torch.distributed.all_reduce(a)
+                torch.distributed.all_reduce(a, group=self.reducer.group)

@@ -57,6 +57,7 @@ SIGNATURES = {
     'vqa_gemm_bf16': (i32, [C.POINTER(VqaGemmDesc), vp]),
     'vqa_gemm_profile': (None, [i32, i32]),
     'vqa_gemm_profile_collect': (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'vqa_gemm_profile_collect2': (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     'vqa_set_gemm_ws': (None, [i32]),
     'vqa_set_gemm_use_tr': (None, [i32]),
     'vqa_set_gemm_pipeline': (None, [i32]),

@@ -64,6 +64,9 @@ class _ResumableBackward:
             self._pending_backward = gen
         except StopIteration as done:               # nothing to split (split point outside the layer range)
             G = done.value
+        # the views handed to autograd now are FILLED LATER (resume_backward): correct only while ``p.grad`` IS that view
+        # (AccumulateGrad steals it); graph.GraphedTrainStep checks every parameter's gradient storage against this one
+        self._split_arena_ptr = next(iter(G.values())).untyped_storage().data_ptr()
         return G
 
     def resume_backward(self, to_end: bool = True):

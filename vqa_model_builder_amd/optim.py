@@ -37,7 +37,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self._shadow_sets = []
         self._tables = {}
         self._norm2 = None
-        self._hyper = None                                # HIP-graph mode: per group device floats {lr, step}
+        self._hyper = None                                # device-side schedule: one {lr, step} float pair per STEP CLASS (the parameters of a
+                                                          # group that share a step count); None = lr / bias corrections passed by value
+        self._hyper_gi, self._hyper_lr, self._hyper_of = [], [], {}      # class -> group index, the lr last written to it, id(parameter) -> class
+        self._hyper_key, self._epoch = [], 0              # class -> (group, step count at creation, step() call that created it)
         self._staging = {}                                # HIP-graph mode: pinned host rows per job table
         self.grad_prescale = 1.0                          # DP: gradients hold the all-reduced SUM; 1/world is applied here
         self.wire_grads = None                            # DP captured step with bf16 buckets: id(parameter) -> device address of its all-reduced
@@ -51,18 +54,47 @@ class FusedAdamW(torch.optim.Optimizer):
         return self
 
     def make_capturable(self, device):
-        """HIP-graph mode: learning rate and step count live in device memory ({lr, step} per group), are advanced by a
-        device-side add that is part of the captured step, and the update kernel derives the bias corrections from them
-        -- a replayed graph then follows the schedule instead of repeating the captured step's constants.  Call before
-        the capture, after any eager warm-up steps; all parameters of a group must share one step count."""
-        self._hyper = []
-        for group in self.param_groups:
-            steps = {int(self.state[p]['step']) for p in group['params'] if p in self.state and self.state[p] and not hasattr(p, '_vqa_step')}
-            if len(steps) > 1:
-                raise RuntimeError('FusedAdamW.make_capturable: parameters of one group have different step counts')
-            self._hyper.append(torch.tensor([float(group['lr']), float(steps.pop() if steps else 0)], dtype=torch.float32).to(device))
+        """Device-side schedule: learning rate and step count live in device memory -- one {lr, step} pair per STEP CLASS, i.e. per set of
+        parameters of a group that share a step count (torch's AdamW keeps ``step`` per parameter: a checkpoint may hold several values, and a
+        parameter that receives its first gradient late starts its own bias corrections) -- the count is advanced by a device-side add that is
+        part of the (captured) step and the update kernel derives the bias corrections from it: a replayed graph follows the schedule instead
+        of repeating the captured step's constants, and a step skipped for non-finite fp16 gradients does not count.  Call before a capture,
+        after any eager warm-up steps.  ``step()`` copies a changed ``group['lr']`` to the device words itself whenever it runs outside a
+        stream capture; between REPLAYS of a captured step call ``refresh_lr()`` (``GraphedTrainStep`` does)."""
+        self.sync_step_counts()                           # already device-side: the host copies first, they define the classes
+        self._hyper, self._hyper_gi, self._hyper_lr, self._hyper_of, self._hyper_key = [], [], [], {}, []
+        self._hyper_dev = torch.device(device)
+        self._epoch += 1
+        for gi, group in enumerate(self.param_groups):
+            for p in group['params']:
+                self._class_of(gi, p)
         self._staging = {slot: torch.empty(tuple(c[1].shape), dtype=torch.int64).pin_memory() for slot, c in self._tables.items()}
         return self
+
+    def _class_of(self, gi, p):
+        """Step class of parameter ``p`` (group ``gi``): created on first sight -- never inside a stream capture, where neither the allocation
+        nor the initialising fill would be legal / replay-safe."""
+        ci = self._hyper_of.get(id(p))
+        if ci is not None:
+            return ci
+        st = self.state.get(p)
+        # an expert under dense MoE dispatch counts its own updates (``_vqa_step``): its class only carries the learning rate
+        step0 = -1 if hasattr(p, '_vqa_step') else (int(st['step']) if st else 0)
+        key = (gi, step0, self._epoch)                     # classes are shared only among parameters that join in the same call: an older
+        if key in self._hyper_key:                         # class with the same starting count has advanced since
+            ci = self._hyper_key.index(key)
+        else:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('FusedAdamW: a parameter without a device-side step class received its first gradient inside a stream capture; '
+                                   'run one eager step in the capture\'s configuration before make_capturable()')
+            lr = float(self.param_groups[gi]['lr'])
+            self._hyper.append(torch.tensor([lr, float(max(step0, 0))], dtype=torch.float32).to(self._hyper_dev))
+            self._hyper_gi.append(gi)
+            self._hyper_lr.append(lr)
+            self._hyper_key.append(key)
+            ci = len(self._hyper) - 1
+        self._hyper_of[id(p)] = ci
+        return ci
 
     # ---- loss scaling (fp16 operand mode) -----------------------------------------------------------------------------
     def _amp_state(self, device):
@@ -85,27 +117,32 @@ class FusedAdamW(torch.optim.Optimizer):
         return self._amp is not None and float(self._amp[2]) != 0.0
 
     def refresh_lr(self):
-        """Copies the groups' current ``lr`` to the device words (call between replays when a scheduler changed it)."""
+        """Copies every group's current ``lr`` to the device words of its step classes where it changed (one small fill per changed class;
+        nothing when the schedule did not move).  ``step()`` calls it outside stream captures; call it between replays of a captured step."""
         if self._hyper is not None:
-            for group, h in zip(self.param_groups, self._hyper):
-                h[0:1].fill_(float(group['lr']))
+            for i, h in enumerate(self._hyper):
+                lr = float(self.param_groups[self._hyper_gi[i]]['lr'])
+                if lr != self._hyper_lr[i]:
+                    h[0:1].fill_(lr)
+                    self._hyper_lr[i] = lr
 
     def note_replays(self, n=1):
         """Kept for callers of round 1: the step count of a capturable optimiser lives on the device (``hyper[1]``) and the
         python-side ``state[p]['step']`` is read back from it on demand (``sync_step_counts``), so nothing to note."""
 
     def sync_step_counts(self):
-        """Capturable mode: ``state[p]['step']`` := the device step count of the parameter's group -- the number of updates
+        """Device-side schedule: ``state[p]['step']`` := the device step count of the parameter's step class -- the number of updates
         actually APPLIED (the capture pass applies none; a step skipped for non-finite fp16 gradients does not count).  One
-        host read per group; called by ``state_dict()``."""
+        host read per class; called by ``state_dict()``."""
         if self._hyper is None:
             return
-        for group, h in zip(self.param_groups, self._hyper):
-            n = int(round(float(h[1])))
+        counts = [int(round(float(h[1]))) for h in self._hyper]
+        for group in self.param_groups:
             for p in group['params']:
-                if p in self.state and self.state[p]:
+                ci = self._hyper_of.get(id(p))
+                if ci is not None and p in self.state and self.state[p]:
                     own = getattr(p, '_vqa_step', None)      # an expert's parameters: the updates the expert received
-                    self.state[p]['step'] = n if own is None else int(round(float(own)))
+                    self.state[p]['step'] = counts[ci] if own is None else int(round(float(own)))
 
     def state_dict(self):
         self.sync_step_counts()
@@ -125,11 +162,15 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         lib, st = K.L(), K._stream()
+        self._epoch += 1
         if self._amp_cfg is not None and self._hyper is None:
             # a step skipped for non-finite gradients must not advance the bias corrections: count on the device from the start
             first = next((p for g in self.param_groups for p in g['params'] if p.grad is not None), None)
             if first is not None:
                 self.make_capturable(first.device)
+        if self._hyper is not None and not torch.cuda.is_current_stream_capturing():
+            self.refresh_lr()                              # a scheduler moved group['lr'] since the last step (reference loop: LambdaLR warm-up
+                                                           # from 0, scheduler.step() per step -- training_pipeline.py:311-318,510)
         shadows, shadow_sets = self._shadow_map()
         updated = set()
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
@@ -172,7 +213,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     if ent is None:
                         ent = counted[id(s_all)] = (a_all, s_all, {})
                     ent[2].setdefault(e, prev_step)
-                launches.setdefault((gi, state['step']), []).append(
+                launches.setdefault((gi, state['step']) if self._hyper is None else (gi, -1 - self._class_of(gi, p)), []).append(
                     (p.data_ptr(), gptr, state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
                      act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0))
                 dev = p.device
@@ -202,8 +243,6 @@ class FusedAdamW(torch.optim.Optimizer):
                     cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks))
                 self._tables[slot] = cached
             tables.append((self.param_groups[gi], step, cached[1], cached[2], cached[3], gi))
-        if self._hyper is not None and len(tables) != len({t[5] for t in tables}):
-            raise RuntimeError('FusedAdamW (capturable): parameters of one group have different step counts')
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         amp = None
         if self._amp_cfg is not None:
@@ -223,7 +262,7 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group['betas']
             hyper = None
             if self._hyper is not None:
-                hyper = self._hyper[gi]
+                hyper = self._hyper[-1 - step]                 # the table's step class (keys of device-side tables are (group, -1 - class))
                 # device-side step += 1 (captured with the step) unless this step's gradients are non-finite
                 K._chk(lib.vqa_opt_advance(hyper.data_ptr(), self._norm2.data_ptr() if amp is not None else None, st), 'vqa_opt_advance')
             K._chk(lib.vqa_adamw_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr() if (clip or amp is not None) else None,
