@@ -390,7 +390,7 @@ GEN_TINY = dict(TINY, gen_vocab=96, gen_heads=4, gen_layers=2, gen_ff=96, answer
 GEN_FULL = dict(FULL, gen_vocab=64000, gen_heads=8, gen_layers=6, gen_ff=2048, answer_len=16, batch=2)
 
 
-def build_reference_generative(dims):
+def build_reference_generative(dims, use_moe=False, moe_type='standard'):
     """The reference's ``GenerativeVQAModel`` (generative_vqa_model.py:479-598) with the two hub-name loaders replaced by local
     random-weight construction of the same HF classes, as for the classification model."""
     import transformers
@@ -410,7 +410,7 @@ def build_reference_generative(dims):
     try:
         cfg = gm.GenerativeVQAConfig(hidden_size=d['D'], fusion_dim=d['D'], num_decoder_layers=d['gen_layers'], num_attention_heads=d['gen_heads'],
                                      decoder_ff_dim=d['gen_ff'], max_answer_length=max(d['answer_len'], 8), fusion_num_heads=d['fusion_heads'],
-                                     fusion_num_layers=d['fusion_layers'], vocab_size=d['gen_vocab'], use_moe=False)
+                                     fusion_num_layers=d['fusion_layers'], vocab_size=d['gen_vocab'], use_moe=use_moe, moe_type=moe_type)
         model = gm.GenerativeVQAModel(cfg).eval()
     finally:
         transformers.CLIPVisionModel.from_pretrained, gm.AutoModel = old_clip, old_auto
@@ -432,14 +432,44 @@ def make_decoder_inputs(dims, seed):
     return dec_in, dmask, labels
 
 
-def run_generative_case(tag, dims, seed, full_logits):
-    model, cfg = build_reference_generative(dims)
+def _router_gap(model, kw):
+    """Smallest gap between the k-th and (k+1)-th router probability over all tokens of the fusion MoE (eval forward, no grad)."""
+    moe = model.fusion.moe_layer
+    with torch.no_grad():
+        model(**{k: v for k, v in kw.items() if k != 'labels'})
+    p = moe.aux_outputs['router_probs'].reshape(-1, moe.num_experts)
+    srt = p.sort(dim=-1, descending=True).values
+    return float((srt[:, moe.top_k - 1] - srt[:, moe.top_k]).min()), p
+
+
+def run_generative_case(tag, dims, seed, full_logits, use_moe=False, moe_type='standard', tries=1):
+    """``use_moe``: the reference's fusion MoE over the 114 (tiny: 13) concatenated tokens (generative_vqa_model.py:224-339): moe_type 'vqa'
+    = VQAMOELayer (Vision / Text / Multimodal / Segmentation experts ATTENDING ACROSS the tokens of a sample, NoisyTopK router), 'standard'
+    = MOELayer(config=...) (FeedForward experts, TopK router).  Top-k routing of B x 114 tokens is discrete and the router probabilities of
+    random-weight models are close to uniform: of ``tries`` seeds the one with the LARGEST smallest gap between a token's k-th and (k+1)-th
+    probability is kept, and the reference's expert choice is stored (``expert_indices``) so that a parity test can hold the discrete
+    decisions fixed where a 16-bit run lands inside a numerical tie (and must agree everywhere else)."""
+    model, cfg = build_reference_generative(dims, use_moe, moe_type)
     shapes = dw.shapes_of(model.state_dict())
-    sd = dw.make_state_dict(shapes, seed)
-    model.load_state_dict(sd)
-    px, ids, mask, _ = dw.make_inputs(dims['batch'], dims['seq'], dims['image'], vocab_hi=min(30000, dims['vocab']), num_answers=8, seed=seed)
-    dec_in, dmask, labels = make_decoder_inputs(dims, seed)
-    kw = dict(pixel_values=px, input_ids=ids, attention_mask=mask, decoder_input_ids=dec_in, decoder_attention_mask=dmask, labels=labels)
+
+    def setup(sd_seed):
+        sd_ = dw.make_state_dict(shapes, sd_seed)
+        model.load_state_dict(sd_)
+        px_, ids_, mask_, _ = dw.make_inputs(dims['batch'], dims['seq'], dims['image'], vocab_hi=min(30000, dims['vocab']), num_answers=8, seed=sd_seed)
+        dec_in_, dmask_, labels_ = make_decoder_inputs(dims, sd_seed)
+        return sd_, dict(pixel_values=px_, input_ids=ids_, attention_mask=mask_, decoder_input_ids=dec_in_, decoder_attention_mask=dmask_, labels=labels_)
+    best = (-1.0, seed)
+    if use_moe and tries > 1:
+        for t in range(tries):
+            _, kw_t = setup(seed + 1000 * t)
+            gap, _ = _router_gap(model, kw_t)
+            print(f'[gen_golden] {tag}: seed {seed + 1000 * t}: smallest router gap {gap:.2e}', flush=True)
+            best = max(best, (gap, seed + 1000 * t))
+        seed = best[1]
+    sd, kw = setup(seed)
+    px, ids, mask, dec_in, dmask, labels = (kw[k] for k in ('pixel_values', 'input_ids', 'attention_mask', 'decoder_input_ids', 'decoder_attention_mask', 'labels'))
+    routed = {}
+    hook = model.fusion.moe_layer.router.register_forward_hook(lambda m, i, o: routed.update(w=o[0].detach(), idx=o[1].detach())) if use_moe else None
     with torch.enable_grad():
         out = model(**kw)
         out.loss.backward()
@@ -447,6 +477,15 @@ def run_generative_case(tag, dims, seed, full_logits):
     arrays = {'loss': out.loss.detach().numpy(), 'memory': out.encoder_hidden_states.detach().numpy(),
               'logits' if full_logits else 'logits_sample': (logits0 if full_logits else logits0.flatten()[::97]).numpy(),
               'argmax': logits0.argmax(-1).numpy()}
+    if use_moe:
+        hook.remove()
+        moe = model.fusion.moe_layer
+        arrays['router_probs'] = moe.aux_outputs['router_probs'].detach().numpy()
+        arrays['load_balance_loss'] = np.float64(float(moe.aux_outputs['load_balance_loss']))
+        arrays['expert_indices'] = routed['idx'].numpy()              # what the reference's router returned in THIS forward
+        arrays['routing_weights'] = routed['w'].numpy()
+        srt = np.sort(arrays['router_probs'].reshape(-1, moe.num_experts), axis=-1)[:, ::-1]
+        arrays['router_gap'] = (srt[:, moe.top_k - 1] - srt[:, moe.top_k]).reshape(arrays['router_probs'].shape[:2])
     top2 = logits0.topk(2, dim=-1).values
     arrays['margin'] = (top2[..., 0] - top2[..., 1]).numpy()
     grad_names, none_names, grads0 = [], [], {}
@@ -478,7 +517,7 @@ def run_generative_case(tag, dims, seed, full_logits):
     model.zero_grad(set_to_none=True)
     meta = dict(tag=tag, dims=dims, seed=seed, shapes={k: list(v) for k, v in shapes.items()}, keys=list(shapes), grad_names=grad_names,
                 none_grad_names=none_names, weights_checksum=dw.checksum(sd), torch=torch.__version__,
-                transformers=__import__('transformers').__version__)
+                transformers=__import__('transformers').__version__, use_moe=bool(use_moe), moe_type=moe_type, min_router_gap=float(best[0]))
     arrays['meta'] = np.array(json.dumps(meta))
     path = os.path.join(OUT, f'{tag}.npz')
     np.savez_compressed(path, **arrays)
@@ -606,6 +645,13 @@ def main():
         # the generative model: tiny with full logits, full-size (64 000-way head) with a logits sample
         run_generative_case('generative_tiny', GEN_TINY, 41, True)
         run_generative_case('generative_full', GEN_FULL, 42, False)
+    if args.only in ('all', 'generative', 'generative_moe', 'generative_moe_tiny'):
+        # BASELINE configs[4] territory: the generative model WITH its fusion MoE over the 114 concatenated tokens
+        run_generative_case('generative_tiny_moe_vqa', GEN_TINY, 43, True, use_moe=True, moe_type='vqa', tries=24)
+        run_generative_case('generative_tiny_moe_std', GEN_TINY, 44, True, use_moe=True, moe_type='standard', tries=24)
+        if args.only != 'generative_moe_tiny':
+            run_generative_case('generative_full_moe_vqa', GEN_FULL, 45, False, use_moe=True, moe_type='vqa', tries=12)
+            run_generative_case('generative_full_moe_std', GEN_FULL, 46, False, use_moe=True, moe_type='standard', tries=12)
     if args.only in ('all', 'fusion'):
         for i, (tag, case) in enumerate(FUSION_CASES.items()):
             run_fusion_case(tag, case, 51 + i)

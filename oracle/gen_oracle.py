@@ -2,7 +2,9 @@
 
 Follows ``src/modeling/meta_arch/generative_vqa_model.py``: VisualEncoder :141-151 (all CLIP tokens), QuestionEncoder :175-190,
 CrossModalFusion :286-339 (concatenated sequence through pre-LN ``nn.TransformerEncoderLayer`` x N with the question's padding
-mask, LayerNorm; MoE off), TransformerDecoder :383-451 (tied embedding + sinusoidal positions, pre-LN ``nn.TransformerDecoderLayer``
+mask, optional MoE over all tokens :224-284,326-337 -- moe_type 'vqa' = VQAMOELayer with the default one-of-each expert mix, 'standard' =
+MOELayer of FeedForward experts behind a TopK router; its load-balance statistic enters the loss as a python float :590-591 --, LayerNorm),
+TransformerDecoder :383-451 (tied embedding + sinusoidal positions, pre-LN ``nn.TransformerDecoderLayer``
 x N with causal + padding masks, LayerNorm, tied output projection), GenerativeVQAModel.forward :523-598 (label-smoothed cross
 entropy, ignore_index -100).  ``torch.nn`` layer algorithms (norm_first encoder / decoder layers, eval mode) restated from their
 published definitions; pinned by tests/golden/generative_*.npz, produced by the reference itself (oracle/gen_golden.py --only
@@ -64,9 +66,29 @@ def _count(sd, fmt):
     return n
 
 
+def fusion_moe(sd, fused, top_k=2, moe_loss_weight=0.01, router_out=None):
+    """The fusion MoE when the state dict holds one (``fusion.moe_layer.*``): returns (output, aux).  Expert kinds from the parameter
+    names: VQAMOELayer's mix (vqa_oracle.vqa_moe_expert_kinds; generative_vqa_model.py:232-245: one Vision / Text / Multimodal / Segmentation
+    expert by default, NoisyTopK router = clean logits in eval) or FeedForward experts (``experts.N.fc1``: MOELayer(config=...), TopK router
+    whose load-balance weight is config.moe_loss_weight :249-255,266-283).  Every expert sees ALL tokens of a sample (moe_layer.py:151-168)."""
+    p = 'fusion.moe_layer.'
+    n = _count(sd, p + 'experts.{}.output_norm.weight') or _count(sd, p + 'experts.{}.layer_norm.weight')
+    if (p + 'experts.0.fc1.weight') in sd:
+        kinds, lbw = ['feedforward'] * n, moe_loss_weight
+    else:
+        kinds, lbw = [], 0.01
+        for e in range(n):
+            q = f'{p}experts.{e}.'
+            kinds.append('vision' if q + 'spatial_norm.weight' in sd else 'text' if q + 'attention_norm.weight' in sd else
+                         'segmentation' if q + 'mask_tokens' in sd else 'detection' if q + 'object_queries' in sd else 'multimodal')
+    if router_out is None:
+        router_out = vo.noisy_topk_router(sd, p + 'router.', fused, top_k, None, 1.0, lbw)
+    return vo.moe_layer(sd, p, fused, kinds, top_k, router_out=router_out)
+
+
 def generative_forward(sd, pixel_values, input_ids, attention_mask, decoder_input_ids, decoder_attention_mask=None, labels=None, *,
-                       vit_heads, text_heads, fusion_heads, decoder_heads, label_smoothing=0.1):
-    """Returns (logits [B, A, V], loss | None, encoder_hidden_states)."""
+                       vit_heads, text_heads, fusion_heads, decoder_heads, label_smoothing=0.1, top_k=2, moe_loss_weight=0.01, aux_out=None):
+    """Returns (logits [B, A, V], loss | None, encoder_hidden_states).  ``aux_out``: optional dict that receives the MoE router's aux outputs."""
     vis = vo.clip_vision_forward(sd, 'visual_encoder.vision_model.', pixel_values, vit_heads)
     txt = vo.roberta_forward(sd, 'question_encoder.encoder.', input_ids, attention_mask, text_heads)
     fused = torch.cat([vis, txt], dim=1)
@@ -74,6 +96,12 @@ def generative_forward(sd, pixel_values, input_ids, attention_mask, decoder_inpu
     kpm = torch.cat([torch.zeros(B, nv, dtype=torch.bool), ~attention_mask.bool()], dim=1)
     for i in range(_count(sd, 'fusion.layers.{}.norm1.weight')):
         fused = encoder_layer(sd, f'fusion.layers.{i}.', fused, fusion_heads, kpm)
+    moe_aux = 0.0
+    if 'fusion.moe_layer.router.gate.weight' in sd:
+        fused, aux = fusion_moe(sd, fused, top_k, moe_loss_weight)
+        moe_aux = float(aux['load_balance_loss'])            # .item()-ed in the reference (:333-337): a constant, no gradient
+        if aux_out is not None:
+            aux_out.update(aux)
     memory = vo.layer_norm(sd, 'fusion.layer_norm', fused)
     emb = sd['answer_embedding.weight']
     x = F.embedding(decoder_input_ids, emb) + sd['decoder.pos_encoding.pe'][:, :decoder_input_ids.shape[1]]
@@ -85,6 +113,8 @@ def generative_forward(sd, pixel_values, input_ids, attention_mask, decoder_inpu
     loss = None
     if labels is not None:
         loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=-100, label_smoothing=label_smoothing)
+        if moe_aux > 0:
+            loss = loss + moe_loss_weight * moe_aux          # generative_vqa_model.py:590-591
     return logits, loss, memory
 
 

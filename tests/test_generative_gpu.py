@@ -26,25 +26,51 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
-@pytest.mark.parametrize('tag', ['generative_tiny', 'generative_full'])
-def test_generative_forward_backward_matches_the_reference(tag, mode):
+def _forward_backward(model, meta, scale):
+    model.zero_grad(set_to_none=True)
+    px, ids, mask, dec_in, dmask, labels = [t.to(DEV) for t in go.fixture_inputs(meta)]
+    out = model(pixel_values=px, input_ids=ids, attention_mask=mask, decoder_input_ids=dec_in, decoder_attention_mask=dmask, labels=labels)
+    (out.loss * scale).backward()
+    torch.cuda.synchronize()
+    return out
+
+
+def _check_generative(tag, mode):
     import vqa_model_builder_amd as vqa
     arrays, meta = load_golden(tag)
     d = meta['dims']
     ac, scale = MODES[mode]
     vqa.set_compute_dtype(mode)
     try:
-        model = build_generative_model(d)
+        over = dict(use_moe=True, moe_type=meta['moe_type']) if meta.get('use_moe') else {}
+        model = build_generative_model(d, **over)
         sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
         assert dw.checksum(sd) == meta['weights_checksum']
         assert list(model.state_dict().keys()) == meta['keys']
         model.load_state_dict(sd)
         model = model.to(DEV).eval()
-        px, ids, mask, dec_in, dmask, labels = [t.to(DEV) for t in go.fixture_inputs(meta)]
-        out = model(pixel_values=px, input_ids=ids, attention_mask=mask, decoder_input_ids=dec_in, decoder_attention_mask=dmask, labels=labels)
-        (out.loss * scale).backward()
-        torch.cuda.synchronize()
+        out = _forward_backward(model, meta, scale)
+        route = ''
+        if meta.get('use_moe'):
+            # Top-2 routing of B x 114 tokens is discrete, and random-weight router probabilities sit close together (the fixture keeps the best
+            # of several seeds and records every token's gap): this run's choice must equal the reference's wherever the reference's gap between
+            # the 2nd and 3rd probability exceeds 4 x the measured probability error; tokens INSIDE that band may take the other expert -- the
+            # reference under its own autocast does -- and the continuous comparison below is then made with the reference's choice held fixed
+            # for them (router._forced_indices: the weights stay this run's own probabilities, renormalised).
+            moe = model.fusion.moe_layer
+            probs = moe.aux_outputs['router_probs'].detach().float().cpu().numpy()
+            perr = float(np.abs(probs - arrays['router_probs']).max())
+            got = np.sort(np.argsort(-probs, axis=-1, kind='stable')[..., :moe.top_k], axis=-1)
+            flips = (got != np.sort(arrays['expert_indices'], axis=-1)).any(-1)
+            band = 4.0 * perr + 1e-6
+            assert not (flips & (arrays['router_gap'] > band)).any(), (tag, mode, 'expert choice differs outside a numerical tie', perr, arrays['router_gap'][flips])
+            assert flips.mean() <= 0.05, (tag, mode, 'too many routing ties', int(flips.sum()))
+            assert abs(float(moe.aux_outputs['load_balance_loss']) - float(arrays['load_balance_loss'])) < 1e-3
+            route = f' router_prob_err={perr:.2e} tie_tokens={int(flips.sum())}/{flips.size} min_gap={float(arrays["router_gap"].min()):.2e}'
+            if flips.any():
+                moe.router._forced_indices = torch.from_numpy(arrays['expert_indices']).to(DEV)
+                out = _forward_backward(model, meta, scale)
+                moe.router._forced_indices = None
         logits = out.logits.detach().float().cpu()
         if 'logits' in arrays:
             e_log = rel_l2(logits.numpy(), arrays['logits'])
@@ -80,14 +106,31 @@ def test_generative_forward_backward_matches_the_reference(tag, mode):
         ref_num = sum((float(e) * float(arrays['gnorm/' + n])) ** 2 for e, n in zip(arrays[ac + '/gs'], meta['grad_names']))
         ref_agg = (ref_num / sum(float(arrays['gnorm/' + n]) ** 2 for n in meta['grad_names'])) ** 0.5
         print(f'GENERATIVE tag={tag} mode={mode} logits_rel_l2={e_log:.3e} (reference under autocast {env_log:.3e}) loss_abs={e_loss:.3e} '
-              f'memory_rel_l2={e_mem:.3e} grad_aggregate={agg:.3e} (reference {ref_agg:.3e}) worst={worst}')
+              f'memory_rel_l2={e_mem:.3e} grad_aggregate={agg:.3e} (reference {ref_agg:.3e}) worst={worst}{route}')
         assert e_log <= ENV * env_log, (e_log, env_log)
         assert e_loss <= max(ENV * float(arrays[ac + '/loss_abs']), 2e-3 * abs(float(arrays['loss']))), e_loss
         assert agg <= ENV_GRAD * ref_agg, (agg, ref_agg)
         for name in meta['none_grad_names']:
-            assert named[name].grad is None, name
+            g = named[name].grad
+            assert g is None or float(g.abs().max()) == 0.0, name
     finally:
         vqa.set_compute_dtype('bf16')
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('tag', ['generative_tiny', 'generative_full'])
+def test_generative_forward_backward_matches_the_reference(tag, mode):
+    _check_generative(tag, mode)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+@pytest.mark.parametrize('tag', ['generative_tiny_moe_vqa', 'generative_tiny_moe_std', 'generative_full_moe_vqa', 'generative_full_moe_std'])
+def test_generative_with_fusion_moe_matches_the_reference(tag, mode):
+    """BASELINE configs[4] territory (reference generative_vqa_model.py:224-339): the fusion MoE over all 114 concatenated tokens -- moe_type
+    'vqa' (Vision / Text / Multimodal / Segmentation experts attending ACROSS the tokens of a sample, NoisyTopK router) and 'standard'
+    (FeedForward experts, TopK router) -- teacher-forced forward + backward against fixtures the reference produced, tiny and full size
+    (586 M / 347 M parameters), both operand types, same envelopes as the MoE-free model."""
+    _check_generative(tag, mode)
 
 
 def test_generative_training_mode_and_generate_run():

@@ -78,10 +78,14 @@ def test_oracle_matches_reference_full_batch32(tag):
     _check(tag, False)
 
 
-@pytest.mark.parametrize('tag', ['generative_tiny', 'generative_full'])
+GEN_TAGS = ['generative_tiny', 'generative_full', 'generative_tiny_moe_vqa', 'generative_tiny_moe_std', 'generative_full_moe_vqa', 'generative_full_moe_std']
+
+
+@pytest.mark.parametrize('tag', GEN_TAGS)
 def test_generative_oracle_matches_reference(tag):
-    """oracle/gen_oracle.py (concatenated-sequence pre-LN fusion, causal pre-LN decoder, tied 64 000-way head, label-smoothed CE
-    with ignore_index) against what the reference's own GenerativeVQAModel produced: logits, loss, memory, every gradient."""
+    """oracle/gen_oracle.py (concatenated-sequence pre-LN fusion, optional fusion MoE over all 114 tokens -- VQAMOELayer's expert mix or
+    FeedForward experts --, causal pre-LN decoder, tied 64 000-way head, label-smoothed CE with ignore_index) against what the reference's
+    own GenerativeVQAModel produced: logits, loss, memory, router probabilities / expert choice, every gradient."""
     import torch
     from oracle import det_weights as dw
     from oracle import gen_oracle as go
@@ -97,9 +101,17 @@ def test_generative_oracle_matches_reference(tag):
         leaves[k] = v.clone().requires_grad_(v.is_floating_point() and k != 'decoder.pos_encoding.pe')
     leaves['decoder.embedding.weight'] = leaves['decoder.output_projection.weight'] = leaves['answer_embedding.weight']
     px, ids, mask, dec_in, dmask, labels = go.fixture_inputs(meta)
+    aux = {}
     logits, loss, memory = go.generative_forward(leaves, px, ids, mask, dec_in, dmask, labels, vit_heads=d['vit_heads'], text_heads=d['txt_heads'],
-                                                 fusion_heads=d['fusion_heads'], decoder_heads=d['gen_heads'])
+                                                 fusion_heads=d['fusion_heads'], decoder_heads=d['gen_heads'], aux_out=aux)
     loss.backward()
+    if meta.get('use_moe'):
+        probs = aux['router_probs'].detach().numpy()
+        assert np.abs(probs - arrays['router_probs']).max() < 1e-5
+        assert abs(float(aux['load_balance_loss']) - float(arrays['load_balance_loss'])) < 1e-6
+        got_idx = np.sort(np.argsort(-probs, axis=-1)[..., :2], axis=-1)
+        flips = (got_idx != np.sort(arrays['expert_indices'], axis=-1)).any(-1)
+        assert not (flips & (arrays['router_gap'] > 1e-5)).any()          # the oracle routes every token as the reference did
     rl = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()) / (np.linalg.norm(np.asarray(b, np.float64)) + 1e-30))
     if 'logits' in arrays:
         assert rl(logits.detach().numpy(), arrays['logits']) < 1e-5

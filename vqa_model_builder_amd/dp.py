@@ -339,6 +339,11 @@ class GradReducer:
         self._consume_on_wire = bool(on)
         return self
 
+    def segment_needs_pack(self, name: str) -> bool:
+        """Whether ``pack_segment`` issues any device work for this segment (stand-alone gradients to gather, or bf16 wire copies)."""
+        seg = self._segments[name]
+        return seg['pack'] is not None or seg['stage'] is not None
+
     def pack_segment(self, name: str):
         """Device-side preparation of a segment's exchange (capturable: the tail of the segment's backward graph): gathers the
         stand-alone gradients into the segment's pack buffer and, with bf16 buckets, writes the bfloat16 copies to send."""

@@ -173,6 +173,9 @@ class GraphedTrainStep:
             # the device-side packing of each segment (stand-alone gradients -> pack buffer, bf16 wire copies) is a small graph of
             # its own, replayed right behind the segment's backward graph
             for name in order:
+                if not reducer.segment_needs_pack(name):
+                    self.graphs['pack' + name] = None     # fp32 buckets, every gradient inside an arena: nothing to do (an EMPTY capture is what
+                    continue                              # printed "The CUDA Graph is empty" in round 2's bench log: the dp_model leg's fp32 segments)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, **kw):
                     reducer.pack_segment(name)
@@ -398,8 +401,10 @@ class GraphedTrainStep:
                 if timed:
                     marks[1 + i].record()
                 self.graphs[name].replay()
+                pack = self.graphs['pack' + name]
                 if xs is None:
-                    self.graphs['pack' + name].replay()
+                    if pack is not None:
+                        pack.replay()
                     red.reduce_segment(name)             # asynchronous: travels beside the next segment's graph
                 else:
                     # the segment's whole exchange chain -- wire-format copies (fp32 -> bf16), all-reduce / all-gather, copies back into the
@@ -407,7 +412,8 @@ class GraphedTrainStep:
                     # (1.2 GB each way with bf16 buckets) run beside the next segment's graph instead of in front of / behind it
                     xs.wait_stream(cur)
                     with torch.cuda.stream(xs):
-                        self.graphs['pack' + name].replay()
+                        if pack is not None:
+                            pack.replay()
                         red.reduce_segment(name)
                         red.wait_segment(name)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

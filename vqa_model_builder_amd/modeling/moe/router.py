@@ -28,7 +28,7 @@ class _GateTopKFn(torch.autograd.Function):
     """x [T,D], gate [E,D], w_noise [E,D]|None, noise [T,E]|None -> weights [T,K], indices [T,K], probs_clean [T,E]"""
 
     @staticmethod
-    def forward(ctx, x, gate, w_noise, noise, noise_std, top_k, soft, temperature):
+    def forward(ctx, x, gate, w_noise, noise, noise_std, top_k, soft, temperature, forced=None):
         T, D = x.shape
         E = gate.shape[0]
         dev, st = x.device, K._stream()
@@ -58,6 +58,13 @@ class _GateTopKFn(torch.autograd.Function):
             idx_out = torch.arange(E, device=dev).expand(T, E).contiguous()
         else:
             w_out, idx_out = w, idx
+            if forced is not None:
+                # parity tests only (BaseRouter._forced_indices): the discrete choice is GIVEN -- the reference's own, where a 16-bit run lands
+                # inside a numerical tie of two router probabilities --; the weights are this run's probabilities of those experts,
+                # renormalised (router.py:313-320), and backward differentiates exactly that (vqa_router_topk_bwd takes the indices as data)
+                idx_out = forced.reshape(T, kk).to(torch.int64).contiguous()
+                w_out = probs.gather(1, idx_out)
+                w_out = w_out / w_out.sum(dim=1, keepdim=True)
         ctx.save_for_backward(x, gate, w_noise, noise, nraw, logits, idx_out)
         ctx.meta = (T, E, D, kk, noise_std, soft, temperature)
         ctx.mark_non_differentiable(idx_out, probs_clean)
@@ -78,7 +85,7 @@ class _GateTopKFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         K._chk(_lib().vqa_router_gate_bwd(x.data_ptr(), gate.data_ptr(), K._p(w_noise), K._p(noise), noise_std, K._p(nraw), dlog.data_ptr(),
                                           dgate.data_ptr(), K._p(dwn), dx.data_ptr(), T, E, D, st), 'vqa_router_gate_bwd')
-        return dx, dgate, (dwn if noise is not None else None), None, None, None, None, None
+        return dx, dgate, (dwn if noise is not None else None), None, None, None, None, None, None
 
 
 def _aux_loss(probs_clean, idx, E, kk, weight):
@@ -95,6 +102,7 @@ class BaseRouter(ABC, nn.Module):
         super().__init__()
         self.input_dim, self.num_experts, self.top_k = input_dim, num_experts, top_k
         self.gate = nn.Linear(input_dim, num_experts, bias=False)
+        self._forced_indices = None       # tests: int64 [B,S,K] standing for torch.topk's choice (see _GateTopKFn.forward)
 
     @abstractmethod
     def forward(self, x: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, Any]]:
@@ -104,7 +112,8 @@ class BaseRouter(ABC, nn.Module):
         if not x.is_cuda:
             raise RuntimeError('router: HIP path needs GPU tensors; no CPU fallback on the product path')
         B, S, D = x.shape
-        w, idx, probs = _GateTopKFn.apply(x.reshape(B * S, D), self.gate.weight, w_noise, noise, noise_std, self.top_k, soft, temperature)
+        w, idx, probs = _GateTopKFn.apply(x.reshape(B * S, D), self.gate.weight, w_noise, noise, noise_std, self.top_k, soft, temperature,
+                                          None if soft else self._forced_indices)
         kk = w.shape[-1]
         return w.view(B, S, kk), idx.view(B, S, kk), probs.view(B, S, -1)
 

@@ -78,8 +78,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if ci is not None:
             return ci
         st = self.state.get(p)
-        # an expert under dense MoE dispatch counts its own updates (``_vqa_step``): its class only carries the learning rate
-        step0 = -1 if hasattr(p, '_vqa_step') else (int(st['step']) if st else 0)
+        # (an expert under dense MoE dispatch counts its own updates on the device -- ``_vqa_step``, which overrides the class count in the
+        # kernel's bias corrections --; it stays in the class its host-side step puts it in, so the job tables keep the partition the eager
+        # warm-up steps built and a capture finds every table allocated)
+        step0 = int(st['step']) if st else 0
         key = (gi, step0, self._epoch)                     # classes are shared only among parameters that join in the same call: an older
         if key in self._hyper_key:                         # class with the same starting count has advanced since
             ci = self._hyper_key.index(key)
