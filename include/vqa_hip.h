@@ -72,6 +72,13 @@ typedef struct VqaGemmGroupItem {
     int M, N, K, lda, ldb, ldc;
 } VqaGemmGroupItem;
 int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);   /* a_kc == b_kc */
+/* The same with the optimiser's global-norm reduction riding along: sumsq (optional device fp32 scalar, caller-initialised) += the sum of
+ * squares of every value written to the outputs (torch.nn.utils.clip_grad_norm_, training_pipeline.py:497, needs exactly this over all
+ * gradients: the weight gradients' share is taken where they are produced instead of re-reading 4 B per parameter).  Weight-gradient items
+ * (a_kc == b_kc == 0) whose rows / columns are multiples of 256 and whose token count is a multiple of 64 run on 256 x 256 tiles, one
+ * 8-wave workgroup per CU (csrc/gemm_dw256.h); vqa_set_gemm_dw256(0) sends everything through the 128 x 128 / 64 x 64 ring kernel. */
+int vqa_gemm_bf16_grouped2(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, float* sumsq, vqa_stream_t s);
+void vqa_set_gemm_dw256(int on);
 /* Measurement (bench.py): while on, every GEMM dispatch carries a start / stop event pair that receives the kernel's own begin /
  * end timestamps (hipExtLaunchKernel) -- the durations rocprofv3 --kernel-trace reports; `tag` labels the launches that follow.
  * vqa_gemm_profile_collect waits for the recorded launches and returns, per tag < ntags, their summed 2*M*N*K FLOP, kernel
@@ -84,7 +91,8 @@ void vqa_set_gemm_ws(int mode);           /* one-tile-per-CU loader/consumer GEM
 void vqa_set_gemm_grid_cap(int cap);      /* > 0: LDS-DMA GEMMs run persistent on at most `cap` workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_force(int cfg, int stages);   /* diagnostics: tile id (0: 128x128, 1: 64x64, 4: 128x64, 5: 64x128; -1: heuristics) for every LDS-DMA launch */
 void vqa_set_gemm_tile_order(int order);         /* 0 / 1 (default): row-major tile ids; 2: column-major (an XCD owns output columns: every weight line fetched by ONE XCD) -- lab */
-void vqa_set_gemm_k_rotate(int on);             /* 1: workgroups of XCD x start their k loop x/8 of the way through K (one HBM fetch per weight line instead of eight concurrent misses) */
+void vqa_set_gemm_k_rotate(int on);             /* low byte 1: workgroups of XCD x start their k loop x/8 of the way through K (one HBM fetch per weight line instead of eight concurrent misses); 2: the grouped launches too;
+                                                 * bits 8..10: a phase added to x (another assignment of starting points = another fp32 summation order: tests) */
 void vqa_set_gemm_group_persistent(int n); /* > 0: grouped launches run persistent on at most n workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */

@@ -930,6 +930,65 @@ def test_fused_adamw_follows_a_warmup_schedule_and_keeps_per_parameter_steps_in_
     assert [int(opt2.state[p]['step']) for p in mine] == [10, 10, 7]
 
 
+def test_grouped_weight_gradients_on_256_tiles_are_exact_and_carry_their_sum_of_squares():
+    """vqa_gemm_bf16_grouped2: the weight-gradient GEMMs dW = dY^T X of a backward pass in one grouped call.  Items whose outputs are
+    256-aligned (and whose token count is a multiple of 64) run on the 256 x 256 / 8-wave kernel (csrc/gemm_dw256.h), the rest on the ring
+    kernel: on integer data every output must equal the exact product whichever kernel ran it (also with the big tiles switched off), for
+    1 .. 32 k-tiles (odd and even counts: both LDS buffers end the loop) and strided operands (the packed q|k|v gradient's column blocks);
+    ``sumsq`` must receive the sum of squares of everything written, once."""
+    import ctypes as C
+    L = hl.load()
+    g = torch.Generator().manual_seed(3)
+
+    def ints(shape):
+        return torch.randint(-3, 4, shape, generator=g).float().to(DEV).to(BF)
+    # (tokens, out rows, in columns): eligible and not
+    cases = [(2048, 768, 768), (1600, 2304, 768), (2048, 768, 3072), (64, 256, 256), (192, 512, 256), (320, 256, 768), (2048, 512, 768), (1600, 768, 200),
+             (96, 256, 256), (128, 3000, 512)]
+    try:
+        for big in (1, 0):
+            L.vqa_set_gemm_dw256(big)
+            items = (hl.VqaGemmGroupItem * len(cases))()
+            keep, outs, refs = [], [], []
+            for it, (T, No, Ki) in zip(items, cases):
+                dy_full, x = ints((T, No + 64)), ints((T, Ki))
+                dy = dy_full[:, 32:32 + No] if No % 8 == 0 and No != 3000 else ints((T, No))        # a column block of a wider tensor (ld > rows)
+                if dy.data_ptr() % 16:
+                    dy = dy.contiguous()
+                out = torch.full((No, Ki), float('nan'), device=DEV)
+                it.a, it.b, it.c_f32 = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+                it.M, it.N, it.K, it.lda, it.ldb, it.ldc = No, Ki, T, dy.stride(0), Ki, Ki
+                keep += [dy_full, dy, x]
+                outs.append(out)
+                refs.append(dy.float().t() @ x.float())
+            ssq = torch.zeros(1, device=DEV)
+            rc = L.vqa_gemm_bf16_grouped2(items, len(cases), 0, 0, ssq.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+            for c, o, r in zip(cases, outs, refs):
+                assert torch.equal(o, r), (big, c, float((o - r).abs().max()))
+            want = sum(float((r.double() ** 2).sum()) for r in refs)
+            assert abs(float(ssq) - want) <= 1e-5 * want, (big, float(ssq), want)
+    finally:
+        L.vqa_set_gemm_dw256(1)
+    # real-valued data: the two kernels agree to fp32 summation-order noise
+    T, No, Ki = 2048, 768, 3072
+    dy, x = rnd((T, No), 5).to(DEV).to(BF), rnd((T, Ki), 6).to(DEV).to(BF)
+    res = []
+    for big in (1, 0):
+        L.vqa_set_gemm_dw256(big)
+        out = torch.empty((No, Ki), device=DEV)
+        items = (hl.VqaGemmGroupItem * 1)()
+        items[0].a, items[0].b, items[0].c_f32 = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+        items[0].M, items[0].N, items[0].K, items[0].lda, items[0].ldb, items[0].ldc = No, Ki, T, No, Ki, Ki
+        assert L.vqa_gemm_bf16_grouped2(items, 1, 0, 0, None, torch.cuda.current_stream().cuda_stream) == 0
+        res.append(out)
+    L.vqa_set_gemm_dw256(1)
+    ref = dy.float().t() @ x.float()
+    for o in res:
+        assert ((o - ref).norm() / ref.norm()).item() < 1e-5
+
+
 def test_fp16_library_gemm_layouts_exact_and_library_switch():
     """The fp16 build (libvqa_hip_f16.so, v_mfma_f32_16x16x32_f16): same layouts, exact on integer data; the operand type is a
     process-wide switch and both handles stay usable."""
@@ -994,7 +1053,8 @@ def test_gemm_k_rotation_is_exact_on_integer_data_and_only_reorders_the_sum():
     def ints(shape):
         return torch.randint(-3, 4, shape, generator=g).float().to(DEV).to(BF)
     try:
-        for (M, N, Kd) in [(66, 2304, 768), (32, 2048, 4096), (2048, 768, 3072), (1600, 768, 768), (100, 96, 1000), (136, 136, 520), (2048, 3072, 768)]:
+        for (M, N, Kd) in [(66, 2304, 768), (32, 2048, 4096), (2048, 768, 3072), (1600, 768, 768), (100, 96, 1000), (136, 136, 520), (2048, 3072, 768),
+                           (400, 3072, 768), (400, 768, 3072), (512, 2304, 768), (264, 768, 768)]:        # batch-8 row counts (ragged 128 / 64-row tiles) rotate too
             for a_kc, b_kc in [(True, True), (True, False), (False, False), (False, True)]:
                 if (not a_kc and M % 8) or (not b_kc and N % 8):
                     continue                               # a transposed operand needs 16-byte rows (VQA_ERR_ARG otherwise)
@@ -1002,7 +1062,7 @@ def test_gemm_k_rotation_is_exact_on_integer_data_and_only_reorders_the_sum():
                 b = ints((N, Kd) if b_kc else (Kd, N))
                 ref = (a.float() if a_kc else a.float().t()) @ (b.float().t() if b_kc else b.float())
                 for split in (False, True):
-                    for rot in (0, 1):
+                    for rot in (0, 1, 1 | (3 << 8), 1 | (6 << 8)):          # off, on, on with two other phases (bits 8..10)
                         L.vqa_set_gemm_k_rotate(rot)
                         o = torch.zeros((M, N), device=DEV)
                         K.gemm(a, b, M, N, Kd, Kd if a_kc else M, Kd if b_kc else N, a_kc, b_kc, out_f32=o, allow_split_k=split)

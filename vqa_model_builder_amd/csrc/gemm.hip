@@ -69,8 +69,11 @@ struct GemmArgs {
     float* colsum;                          // optional [N] fp32, pre-zeroed: += column sums of the stored values (bias gradient)
     int tiles_m_cm; unsigned tiles_m_magic; // > 0: COLUMN-major tile order (tile rows of the launch, and ceil(2^32 / tiles_m)): with the XCD remap every XCD then owns
                                             // a range of output COLUMNS, i.e. every weight line is fetched by ONE XCD (and the activations by all eight)
-    int k_rotate;                           // ring kernels: workgroups on XCD x start their k loop x/8 of the way through K (see gemm_v1_body)
+    int k_rotate;                           // ring kernels: workgroups on XCD x start their k loop x/8 of the way through K (see gemm_v1_body); bits 8..10: phase
+                                            // added to x (tests: another assignment of starting points = another fp32 summation order of the same products)
     int epi_dma;                            // epilogue operand staged through LDS by DMA (ring kernels): 0 none, 1 act_grad_of, 2 residual (host: alignment)
+    float* sumsq;                           // optional fp32 scalar: += sum of squares of the values stored to c_f32 (weight gradients: the optimiser's global-norm
+                                            // reduction rides in the GEMM that produces them instead of re-reading 4 B per parameter)
 #ifdef VQA_GEMM_TRACE
     unsigned long long* trace;              // lab builds only (scratch/gemm_lab.hip): 32 s_memtime stamps per workgroup
 #endif
@@ -266,6 +269,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    float ssq = 0.f;
     const int okind = ODMA ? p.epi_dma : 0;
     const int oper_rb = TN * 16 * (okind == 1 ? 2 : 4);                 // bytes per row of the wave tile in the staged operand
     if (ODMA) {
@@ -337,6 +341,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 if (p.drop_p > 0.f) v *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
                 cs += v;                                  // column sums of the stored values BEFORE the residual (bias gradient)
                 if (ODMA ? okind == 2 : p.residual != nullptr) v += rv;
+                ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                 if (p.c_f32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = v;
                 if (p.c_bf16) {
                     h16x4 o;
@@ -347,6 +352,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
         }
         __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
+    }
+    if (p.sumsq) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) atomicAdd(p.sumsq, ssq);
     }
     if (p.colsum) {
         // lanes l, l + LPR, l + 2 LPR ... hold the same 4 columns: fold them, then ONE lane per column group adds
@@ -601,7 +610,7 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     // the way through K and wrap around.  Every XCD reads the whole weight operand; started together at k = 0 all eight miss on the same lines
     // at the same time -- in the step the weights always come from HBM (profiles/r02/gemm_cold_weights.log: +2 - 4 us per launch) -- rotated, a
     // line is fetched from HBM for one XCD and found in the memory-side cache by the other seven.  fp32 accumulation order changes, nothing else.
-    const int rot = (p.k_rotate && nk >= 8) ? (int)(((unsigned)(blockIdx.x & 7) * (unsigned)nk) >> 3) : 0;
+    const int rot = (p.k_rotate && nk >= 8) ? (int)(((unsigned)((blockIdx.x + (p.k_rotate >> 8)) & 7) * (unsigned)nk) >> 3) : 0;
     if (rot) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) da[i].ptr += (unsigned long long)rot * da[i].step;
@@ -797,7 +806,7 @@ void gemm_v1_kernel(const GemmArgs p) {
 // one tail for all of them, and thousands of equal-cost tiles balance over the CUs where a single 768 x 768 output has 144.
 constexpr int MAX_GROUP = 32;
 struct GroupItem { const h16_t* a; const h16_t* b; float* c; int M, N, K, lda, ldb, ldc, tiles_n; unsigned tiles_n_magic; };
-struct GroupArgs { int n; int k_rotate; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
+struct GroupArgs { int n; int k_rotate; float* sumsq; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
@@ -817,6 +826,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const G
         p.alpha = 1.f; p.drop_inv_keep = 1.f; p.tiles_n = it.tiles_n; p.tiles_n_magic = it.tiles_n_magic;
         p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
         p.k_rotate = g.k_rotate;
+        p.sumsq = g.sumsq;
         gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
         __syncthreads();                                     // the ring (epilogue scratch) is free again
     }
@@ -1047,6 +1057,7 @@ int g_k_rotate = 0;        // k rotation per XCD in the ring kernels (vqa_set_ge
                            // dropout, unwanted for inference and for the bitwise properties the eval-mode tests hold.  One box, cfg2 train step:
                            // 7.16 -> 6.94 ms, GEMM sum 5.61 -> 5.36 ms; cfg3 9.58 -> 9.32 ms (profiles/r02/gemm_k_rotate.log)
 int g_k_rotate_grouped = 0;  // k rotation in the grouped weight-gradient launch too (vqa_set_gemm_k_rotate(2)): lab
+int g_k_rotate_phase = 0;    // 0..7, added to the XCD index before the starting point is derived (vqa_set_gemm_k_rotate(1 | phase << 8)): tests
 int g_tile_order = 0;      // 0 / 1: row-major tile ids (default: an XCD owns rows of the output: activations fetched once, weights by every XCD); 2: column-major (lab, see vqa_gemm_bf16)
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
@@ -1147,6 +1158,7 @@ int ws_pick(int M, int N, int K) {
 
 
 #include "fused_attn.h"      // fused in-projection + attention forward (uses the ring / fragment helpers above)
+#include "gemm_dw256.h"      // 256 x 256 weight-gradient tiles (8 waves, one workgroup per CU)
 
 bool g_use_tr = true;
 
@@ -1214,7 +1226,7 @@ extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
 extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }
 extern "C" void vqa_set_gemm_tile_order(int order) { g_tile_order = order; }
-extern "C" void vqa_set_gemm_k_rotate(int on) { g_k_rotate = on != 0; g_k_rotate_grouped = on >= 2; }
+extern "C" void vqa_set_gemm_k_rotate(int on) { g_k_rotate = (on & 0xff) != 0; g_k_rotate_grouped = (on & 0xff) >= 2; g_k_rotate_phase = (on >> 8) & 7; }
 extern "C" void vqa_set_gemm_pipeline(int v1) {
     // diagnostics for tile_hint launches.  0: register-staged double buffer; 2 / 3: LDS-DMA ring with that many stages
     g_use_v1 = v1 != 0; g_force_dma = v1 != 0;
@@ -1249,6 +1261,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.drop_p = d->drop_p; p.drop_inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
     p.drop_seed = d->drop_seed; p.drop_stream = d->drop_stream;
     p.colsum = d->colsum;
+    p.sumsq = nullptr;
     // the launch's ONE global epilogue operand (saved pre-activation or residual, not both) is staged through LDS by DMA
     // (16-byte chunks: row starts and the row end must be 16-byte aligned); see gemm_epilogue
     p.epi_dma = 0;
@@ -1293,7 +1306,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     p.tiles_m_cm = 0; p.tiles_m_magic = 0;
     // only the encoder / fusion GEMMs over all tokens: their weights are what eight XCDs miss on together; the one-token-per-sample launches of the
     // experts and the head (M <= 128) have one or two tile rows, and their parity margins against the reference are the tightest of the path
-    p.k_rotate = g_k_rotate && d->M >= 256;
+    p.k_rotate = (g_k_rotate && d->M >= 256) ? (1 | (g_k_rotate_phase << 8)) : 0;
     // Column-major tile ids (vqa_set_gemm_tile_order(2)): under the XCD remap every XCD then owns a range of output COLUMNS, so every line of
     // the weight operand is fetched from HBM by one XCD instead of missing in eight L2s at once.  MEASURED, NOT ADOPTED (profiles/r02/gemm_tile_order.log):
     // launch by launch with weights streamed from HBM it wins on every shape (2048x2304x768 19.8 -> 16.1 us, dX 2048x3072x768 21.7 -> 18.3) -- but
@@ -1374,19 +1387,15 @@ int g_group_tile = 0;      // 0: heuristic; 1: 64x64; 2: 128x64; 3: 128x128 (dia
 extern "C" void vqa_set_gemm_group_tile(int t) { g_group_tile = t; }
 extern "C" void vqa_set_gemm_group_persistent(int n) { g_group_persistent = n; }
 
-extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t stream_) {
-    if (!items || n <= 0 || n > MAX_GROUP) return VQA_ERR_ARG;
-    long flops = 0, kmin = 1 << 30, t64 = 0;
+int g_dw256 = 1;            // 1 (default): weight-gradient items with 256-aligned outputs and 64-aligned token counts run on 256 x 256 tiles (gemm_dw256.h)
+extern "C" void vqa_set_gemm_dw256(int on) { g_dw256 = on; }
+
+static int grouped_v1(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, float* sumsq, hipStream_t st) {
+    long kmin = 1 << 30, t64 = 0;
     for (int i = 0; i < n; ++i) {
         const VqaGemmGroupItem& d = items[i];
-        if (!d.a || !d.b || !d.c_f32 || d.M <= 0 || d.N <= 0 || d.K <= 0) return VQA_ERR_ARG;
-        if (d.lda % 8 || d.ldb % 8 || d.N % 4 || d.ldc % 4) return VQA_ERR_ARG;
-        if (a_kc ? (d.K % 8) : (d.M % 8)) return VQA_ERR_ARG;
-        if (b_kc ? (d.K % 8) : (d.N % 8)) return VQA_ERR_ARG;
-        if (((uintptr_t)d.a | (uintptr_t)d.b | (uintptr_t)d.c_f32) & 15) return VQA_ERR_ARG;
         t64 += (long)ceil_div(d.M, 64) * ceil_div(d.N, 64);
         kmin = d.K < kmin ? d.K : kmin;
-        flops += 2L * d.M * d.N * d.K;
     }
     // Tile: with thousands of tiles in the grid the per-workgroup DMA rate no longer decides (occupancy is free), bytes per
     // FLOP does: 128x128 once there are >= 3 rounds of them over the 256 CUs, else the 64x64 tile of the single launches.
@@ -1398,7 +1407,8 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     const int bm = tile == 1 ? 64 : (tile == 4 || tile == 5) ? 256 : 128, bn = (tile == 1 || tile == 2) ? 64 : 128;
     GroupArgs g{};
     g.n = n;
-    g.k_rotate = g_k_rotate_grouped;
+    g.k_rotate = g_k_rotate_grouped ? (1 | (g_k_rotate_phase << 8)) : 0;
+    g.sumsq = sumsq;
     long tiles = 0;
     for (int i = 0; i < n; ++i) {
         const VqaGemmGroupItem& d = items[i];
@@ -1409,7 +1419,6 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     }
     // ring depth as for single launches: the third stage pays when k is long and the grid is under two workgroups per CU
     const bool deep = tile == 1 && kmin >= 2048 && tiles < 512;
-    hipStream_t st = (hipStream_t)stream_;
 #define VQA_G(AK, BKC) (tile == 4 ? launch_grouped<256, 128, 2, AK, BKC, 4, 2>(g, st) : tile == 5 ? launch_grouped<256, 128, 3, AK, BKC, 4, 2>(g, st) \
                         : tile == 7 ? launch_grouped<128, 128, 3, AK, BKC>(g, st) \
                         : tile == 3 ? launch_grouped<128, 128, 2, AK, BKC>(g, st) : tile == 2 ? launch_grouped<128, 64, 2, AK, BKC>(g, st) \
@@ -1418,5 +1427,40 @@ extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a
     if (a_kc && b_kc) return VQA_G(true, true);
     return VQA_ERR_ARG;          // mixed layouts: not instantiated (no caller)
 #undef VQA_G
+}
+
+extern "C" int vqa_gemm_bf16_grouped2(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, float* sumsq, vqa_stream_t stream_) {
+    if (!items || n <= 0 || n > MAX_GROUP) return VQA_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        const VqaGemmGroupItem& d = items[i];
+        if (!d.a || !d.b || !d.c_f32 || d.M <= 0 || d.N <= 0 || d.K <= 0) return VQA_ERR_ARG;
+        if (d.lda % 8 || d.ldb % 8 || d.N % 4 || d.ldc % 4) return VQA_ERR_ARG;
+        if (a_kc ? (d.K % 8) : (d.M % 8)) return VQA_ERR_ARG;
+        if (b_kc ? (d.K % 8) : (d.N % 8)) return VQA_ERR_ARG;
+        if (((uintptr_t)d.a | (uintptr_t)d.b | (uintptr_t)d.c_f32) & 15) return VQA_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    if (a_kc || b_kc || !g_dw256 || !g_use_tr) return grouped_v1(items, n, a_kc, b_kc, sumsq, st);
+    // weight gradients (both operands token-major): the big regular outputs on 256 x 256 tiles, everything else as before
+    VqaGemmGroupItem rest[MAX_GROUP];
+    GroupArgs g{};
+    int nrest = 0;
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const VqaGemmGroupItem& d = items[i];
+        if (!dw256_eligible(d)) { rest[nrest++] = d; continue; }
+        tiles += (long)(d.M / 256) * (d.N / 256);
+        if (tiles > 0x3fffffff) return VQA_ERR_ARG;
+        g.tile_end[g.n] = (int)tiles;
+        g.it[g.n++] = GroupItem{(const h16_t*)d.a, (const h16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.N / 256, div_magic(d.N / 256)};
+    }
+    if (g.n) {
+        const int rc = launch_dw256(g, sumsq, st);
+        if (rc) return rc;
+    }
+    return nrest ? grouped_v1(rest, nrest, 0, 0, sumsq, st) : 0;
+}
+extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t stream_) {
+    return vqa_gemm_bf16_grouped2(items, n, a_kc, b_kc, nullptr, stream_);
 }
 #endif  // VQA_GEMM_LAB

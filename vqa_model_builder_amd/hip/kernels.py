@@ -106,12 +106,15 @@ def prefetch_weights(tensors, workgroups=64):
 # (tests/test_parity_gpu.py::test_full_size_properties_batch32) and the parity fixtures are compared in that mode.  Called by the models' forward.
 TRAIN_K_ROTATE = True
 FORCE_K_ROTATE = False       # tests: rotation on in eval mode too (the eval-mode parity fixtures under train-mode numerics)
+K_ROTATE_PHASE = 0           # tests: 0..7, another assignment of k-loop starting points to the XCDs = another summation order of the same products
 _k_rotate_state = None
 
 
 def set_training_numerics(training: bool):
     global _k_rotate_state
     want = (2 if TRAIN_K_ROTATE == 2 else 1) if ((training and TRAIN_K_ROTATE) or FORCE_K_ROTATE) else 0       # 2 (lab): the grouped weight-gradient launch too
+    if want:
+        want |= (K_ROTATE_PHASE & 7) << 8
     if want != _k_rotate_state:
         L().vqa_set_gemm_k_rotate(want)
         _k_rotate_state = want
@@ -199,6 +202,11 @@ def _wgrad_slot():
     return cur, slot
 
 
+WGRAD_SUMSQ = None      # optional device fp32 scalar: every grouped weight-gradient launch adds the sum of squares of what it writes (FusedAdamW's
+                        # global-norm reduction rides in the GEMMs: optim.FusedAdamW.fuse_wgrad_norm); the covered outputs are noted in WGRAD_SUMSQ_COVERED
+WGRAD_SUMSQ_COVERED = None
+
+
 def _launch_group(pending):
     global _group_items
     if _group_items is None:
@@ -210,7 +218,9 @@ def _launch_group(pending):
             # dW[N,K] = dy[M,N]^T x[M,K]: GEMM rows = N, columns = K, reduction over the M tokens
             it.a, it.b, it.c_f32 = _p(dy), _p(x), _p(out)
             it.M, it.N, it.K, it.lda, it.ldb, it.ldc = N, Kd, M, ldy, ldx, out.stride(0)
-        _chk(L().vqa_gemm_bf16_grouped(_group_items, len(chunk), 0, 0, _stream()), 'vqa_gemm_bf16_grouped')
+            if WGRAD_SUMSQ_COVERED is not None:
+                WGRAD_SUMSQ_COVERED.add((out.data_ptr(), N * Kd if out.stride(0) == Kd else -1))
+        _chk(L().vqa_gemm_bf16_grouped2(_group_items, len(chunk), 0, 0, _p(WGRAD_SUMSQ), _stream()), 'vqa_gemm_bf16_grouped2')
 
 
 def wgrad_flush():

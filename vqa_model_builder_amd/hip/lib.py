@@ -109,6 +109,8 @@ SIGNATURES = {
     'vqa_randn_f32': (i32, [vp, u64, u64, u32, vp]),
     'vqa_dropout_f32': (i32, [vp, vp, vp, u64, f32, u64, u32, vp]),
     'vqa_gemm_bf16_grouped': (i32, [vp, i32, i32, i32, vp]),
+    'vqa_gemm_bf16_grouped2': (i32, [vp, i32, i32, i32, vp, vp]),
+    'vqa_set_gemm_dw256': (None, [i32]),
     'vqa_set_gemm_group_tile': (None, [i32]),
     'vqa_set_gemm_group_persistent': (None, [i32]),
     'vqa_set_gemm_grid_cap': (None, [i32]),
@@ -179,6 +181,8 @@ def load(path: str = None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
         fn.restype, fn.argtypes = res, args
+    if os.environ.get('VQA_DW256') is not None:               # A/B experiments only: 0 = weight gradients on the 128 x 128 ring kernel (round 2)
+        lib.vqa_set_gemm_dw256(int(os.environ['VQA_DW256']))
     if os.environ.get('VQA_GEMM_K_ROTATE') is not None:       # A/B experiments only (like VQA_HIP_LIB): per-XCD k rotation of the ring GEMMs off / on
         lib.vqa_set_gemm_k_rotate(int(os.environ['VQA_GEMM_K_ROTATE']))
     if path is None:

@@ -67,7 +67,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._epoch += 1
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
-                self._class_of(gi, p)
+                if self.state.get(p):                    # a parameter that has never been updated gets its class with its FIRST gradient (step()):
+                    self._class_of(gi, p)                # its bias corrections start there, not with the parameters that train from step one
         self._staging = {slot: torch.empty(tuple(c[1].shape), dtype=torch.int64).pin_memory() for slot, c in self._tables.items()}
         return self
 
