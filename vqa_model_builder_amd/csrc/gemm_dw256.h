@@ -57,6 +57,9 @@ __device__ __forceinline__ void gemm_dw256_tile(const DwTile& T, int m0, int n0,
     char* const dst_b = smem + DW_B_OFF + wave * 4096;
     unsigned dbuf = DW_BUF;                                 // LDS offset of the buffer the NEXT tile is staged into (toggles 32768 <-> 0)
     auto issue_a = [&](int i0) {
+#ifdef DW_LAB_NO_DMA
+        return;
+#endif
 #pragma unroll
         for (int i = i0; i < i0 + 2; ++i) {
             unsigned long long addr = pa[i];
@@ -66,6 +69,9 @@ __device__ __forceinline__ void gemm_dw256_tile(const DwTile& T, int m0, int n0,
         }
     };
     auto issue_b = [&](int i0) {
+#ifdef DW_LAB_NO_DMA
+        return;
+#endif
 #pragma unroll
         for (int i = i0; i < i0 + 2; ++i) {
             unsigned long long addr = pb[i];
@@ -103,17 +109,26 @@ __device__ __forceinline__ void gemm_dw256_tile(const DwTile& T, int m0, int n0,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    h16x8 fa[4][2], fb[2][2];
+    h16x8 fa[4][2] = {}, fb[2][2] = {};
+#ifdef DW_LAB_NO_READS      // lab (scratch/dw_lab.sh): the loop without its LDS fragment reads (fragments = whatever the registers hold)
+#define DW_LOAD_A(AH) do { _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[i][0])); asm volatile("" : "+v"(fa[i][1])); } } while (0)
+#define DW_LOAD_B(BH) do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(fb[j][0])); asm volatile("" : "+v"(fb[j][1])); } } while (0)
+#else
 #define DW_LOAD_A(AH) do { _Pragma("unroll") for (int i = 0; i < 4; ++i) { fa[i][0] = dw_frag<0>(fa_addr[(AH) * 4 + i]); fa[i][1] = dw_frag<16384>(fa_addr[(AH) * 4 + i]); } } while (0)
 #define DW_LOAD_B(BH) do { _Pragma("unroll") for (int j = 0; j < 2; ++j) { fb[j][0] = dw_frag<0>(fb_addr[(BH) * 2 + j]); fb[j][1] = dw_frag<16384>(fb_addr[(BH) * 2 + j]); } } while (0)
+#endif
 #define DW_FENCE() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(fa[i][0])); asm volatile("" : "+v"(fa[i][1])); } \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(fb[j][0])); asm volatile("" : "+v"(fb[j][1])); } \
         __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifdef DW_LAB_NO_MMA        // lab: the loop without its MFMAs (the fragments stay live)
+#define DW_MMA(AH, BH) do { __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define DW_MMA(AH, BH) do { __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
             acc[(AH) * 4 + i][(BH) * 2 + j] = VQA_MFMA16(fb[j][ks], fa[i][ks], acc[(AH) * 4 + i][(BH) * 2 + j]); \
         __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
     // One k-tile per iteration, ONE loop body.  The staging of the next tile is unconditional: behind the LAST tile the eight instructions
     // fetch one k-tile beyond the reduction (clamped to the last tile: nobody reads that buffer again) -- a branch-free body is what lets the
     // register allocator keep the 128 accumulator registers in place.
