@@ -76,7 +76,9 @@ int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_
  * squares of every value written to the outputs (torch.nn.utils.clip_grad_norm_, training_pipeline.py:497, needs exactly this over all
  * gradients: the weight gradients' share is taken where they are produced instead of re-reading 4 B per parameter).  Weight-gradient items
  * (a_kc == b_kc == 0) whose rows / columns are multiples of 256 and whose token count is a multiple of 64 run on 256 x 256 tiles, one
- * 8-wave workgroup per CU (csrc/gemm_dw256.h); vqa_set_gemm_dw256(0) sends everything through the 128 x 128 / 64 x 64 ring kernel. */
+ * 8-wave workgroup per CU (csrc/gemm_dw256.h): up to 64 of them per launch, longest reduction first, tiles drawn from a ticket counter
+ * (a 4-byte memset node in front of the launch zeroes it); vqa_set_gemm_dw256(0) sends everything through the 128 x 128 / 64 x 64 ring
+ * kernel.  n <= 128 here (32 through vqa_gemm_bf16_grouped). */
 int vqa_gemm_bf16_grouped2(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, float* sumsq, vqa_stream_t s);
 void vqa_set_gemm_dw256(int on);
 /* Measurement (bench.py): while on, every GEMM dispatch carries a start / stop event pair that receives the kernel's own begin /

@@ -20,14 +20,17 @@ for _ in range(12):
 for _ in range(12):
     cases += layer_items(1600)
 bufs = []
+zero = os.environ.get('DW_ZERO') == '1'
+mk = (lambda *s: torch.zeros(*s, device=dev).to(BF)) if zero else (lambda *s: torch.randn(*s, device=dev).to(BF))
 for (T, No, Ki) in cases:
-    bufs.append((torch.randn(T, No, device=dev).to(BF), torch.randn(T, Ki, device=dev).to(BF), torch.empty(No, Ki, device=dev)))
+    bufs.append((mk(T, No), mk(T, Ki), torch.empty(No, Ki, device=dev)))
 flop = sum(2.0 * T * No * Ki for T, No, Ki in cases)
 st = torch.cuda.current_stream().cuda_stream
 
 def run():
-    for i0 in range(0, len(cases), 32):
-        chunk = list(zip(cases[i0:i0 + 32], bufs[i0:i0 + 32]))
+    step = int(os.environ.get('DW_CHUNK', '128'))
+    for i0 in range(0, len(cases), step):
+        chunk = list(zip(cases[i0:i0 + step], bufs[i0:i0 + step]))
         items = (hl.VqaGemmGroupItem * len(chunk))()
         for it, ((T, No, Ki), (dy, x, out)) in zip(items, chunk):
             it.a, it.b, it.c_f32 = dy.data_ptr(), x.data_ptr(), out.data_ptr()

@@ -177,7 +177,8 @@ def test_frozen_block_skips_weight_gradient_gemms_and_keeps_dx():
     dq0, dkv0, flop0, n0, has0 = run(True)
     assert all(has1) and not any(has0)
     assert torch.equal(dq0, dq1) and torch.equal(dkv0, dkv1)
-    assert n0 == 7 and n1 == 8, (n0, n1)                       # 7 dX GEMMs; the 7 weight gradients are ONE grouped launch
+    assert n0 == 7 and n1 - n0 in (1, 2), (n0, n1)             # 7 dX GEMMs; the 7 weight gradients are ONE grouped call (two launches when some
+                                                               # outputs qualify for the 256 x 256 tiles and some -- the 200-token vision side -- do not)
     assert abs(flop0 / flop1 - 0.5) < 0.02, (flop0, flop1)    # dW = dX in FLOPs for every Linear of the block
 
 

@@ -21,6 +21,7 @@
 #include "attn_core.h"
 #include <hip/hip_ext.h>
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -1430,7 +1431,7 @@ static int grouped_v1(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, 
 }
 
 extern "C" int vqa_gemm_bf16_grouped2(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, float* sumsq, vqa_stream_t stream_) {
-    if (!items || n <= 0 || n > MAX_GROUP) return VQA_ERR_ARG;
+    if (!items || n <= 0 || n > 2 * DW_MAX_ITEMS) return VQA_ERR_ARG;
     for (int i = 0; i < n; ++i) {
         const VqaGemmGroupItem& d = items[i];
         if (!d.a || !d.b || !d.c_f32 || d.M <= 0 || d.N <= 0 || d.K <= 0) return VQA_ERR_ARG;
@@ -1440,27 +1441,27 @@ extern "C" int vqa_gemm_bf16_grouped2(const VqaGemmGroupItem* items, int n, int 
         if (((uintptr_t)d.a | (uintptr_t)d.b | (uintptr_t)d.c_f32) & 15) return VQA_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream_;
-    if (a_kc || b_kc || !g_dw256 || !g_use_tr) return grouped_v1(items, n, a_kc, b_kc, sumsq, st);
-    // weight gradients (both operands token-major): the big regular outputs on 256 x 256 tiles, everything else as before
-    VqaGemmGroupItem rest[MAX_GROUP];
-    GroupArgs g{};
-    int nrest = 0;
-    long tiles = 0;
+    // weight gradients (both operands token-major): the big regular outputs on 256 x 256 tiles (<= 64 items per launch), everything else -- and
+    // every other layout -- through the ring kernel in launches of <= 32
+    const VqaGemmGroupItem* big[2 * DW_MAX_ITEMS];
+    VqaGemmGroupItem rest[2 * DW_MAX_ITEMS];
+    int nbig = 0, nrest = 0;
     for (int i = 0; i < n; ++i) {
-        const VqaGemmGroupItem& d = items[i];
-        if (!dw256_eligible(d)) { rest[nrest++] = d; continue; }
-        tiles += (long)(d.M / 256) * (d.N / 256);
-        if (tiles > 0x3fffffff) return VQA_ERR_ARG;
-        g.tile_end[g.n] = (int)tiles;
-        g.it[g.n++] = GroupItem{(const h16_t*)d.a, (const h16_t*)d.b, d.c_f32, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.N / 256, div_magic(d.N / 256)};
+        if (!a_kc && !b_kc && g_dw256 && g_use_tr && dw256_eligible(items[i])) big[nbig++] = &items[i];
+        else rest[nrest++] = items[i];
     }
-    if (g.n) {
-        const int rc = launch_dw256(g, sumsq, st);
+    for (int i0 = 0; i0 < nbig; i0 += DW_MAX_ITEMS) {
+        const int rc = launch_dw256(big + i0, nbig - i0 < DW_MAX_ITEMS ? nbig - i0 : DW_MAX_ITEMS, sumsq, st);
         if (rc) return rc;
     }
-    return nrest ? grouped_v1(rest, nrest, 0, 0, sumsq, st) : 0;
+    for (int i0 = 0; i0 < nrest; i0 += MAX_GROUP) {
+        const int rc = grouped_v1(rest + i0, nrest - i0 < MAX_GROUP ? nrest - i0 : MAX_GROUP, a_kc, b_kc, sumsq, st);
+        if (rc) return rc;
+    }
+    return 0;
 }
 extern "C" int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t stream_) {
+    if (n > MAX_GROUP) return VQA_ERR_ARG;
     return vqa_gemm_bf16_grouped2(items, n, a_kc, b_kc, nullptr, stream_);
 }
 #endif  // VQA_GEMM_LAB

@@ -189,7 +189,7 @@ def linear_dx(dy_bf16, w_bf16, M, N, K, *, want_f32=False, want_bf16=False, resi
 # Operands are kept alive (referenced by the queue) until the flush.  (Issuing them on a side HIP stream instead -- per GEMM, per
 # layer or per flush -- measured slower or no faster beside the parallel encoder branches and is not offered.)
 WGRAD_GROUPED = True
-WGRAD_GROUP_MAX = 32
+WGRAD_GROUP_MAX = 128     # items per vqa_gemm_bf16_grouped2 call (the library cuts it into launches: <= 64 on 256 x 256 tiles, <= 32 on the ring kernel)
 _wgrad = {}          # main cuda_stream handle -> [unused, unused, pending GEMM argument tuples]
 _group_items = None
 
