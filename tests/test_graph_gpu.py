@@ -38,6 +38,47 @@ def _eager(model, opt, batch, n):
     return out
 
 
+def test_weight_gradient_norm_taken_in_the_gemms_equals_the_norm_pass():
+    """FusedAdamW.fuse_wgrad_norm: the weight gradients' share of the clipping norm is summed by the grouped GEMMs that store them; the step must
+    see the same global norm (fp32 summation order aside) and move the parameters the same way as with the optimiser's own pass over every
+    gradient -- with and without MoE experts (stand-alone parameters), and a second backward accumulated into the first (the covered ranges no
+    longer ARE the gradients) must fall back to the full pass instead of clipping against a stale norm."""
+    for setup in (_setup, _moe_setup):
+        res = []
+        for fused in (False, True):
+            model, opt, batch = setup(False) if setup is _setup else setup()
+            if fused:
+                opt.fuse_wgrad_norm(True)
+            try:
+                norms = []
+                for _ in range(3):
+                    opt.zero_grad(set_to_none=True)
+                    model(**batch).loss.backward()
+                    opt.step()
+                    norms.append(float(opt.grad_norm()))
+                res.append((norms, [p.detach().clone() for p in model.parameters()], opt))
+            finally:
+                opt.fuse_wgrad_norm(False)
+        (n0, p0, _), (n1, p1, o1) = res
+        for a, b in zip(n0, n1):
+            assert abs(a - b) <= 2e-5 * a, (n0, n1)
+        for a, b in zip(p0, p1):
+            assert torch.allclose(a, b, atol=2e-6, rtol=1e-4)
+    # accumulation of two backward passes: the fused bookkeeping must notice and the norm must be that of the SUMMED gradients
+    model, opt, batch = _setup(False)
+    ref_model, ref_opt, _ = _setup(False)
+    opt.fuse_wgrad_norm(True)
+    try:
+        for m, o in ((model, opt), (ref_model, ref_opt)):
+            o.zero_grad(set_to_none=True)
+            m(**batch).loss.backward()
+            m(**batch).loss.backward()
+            o.step()
+        assert abs(float(opt.grad_norm()) - float(ref_opt.grad_norm())) <= 2e-5 * float(ref_opt.grad_norm())
+    finally:
+        opt.fuse_wgrad_norm(False)
+
+
 @pytest.mark.parametrize('towers', [False, True])
 def test_replayed_step_follows_eager_step(towers):
     from vqa_model_builder_amd.graph import GraphedTrainStep

@@ -46,11 +46,13 @@ def build(force=False, verbose=True):
             objs.append(obj)
             if force or _stale(obj, [os.path.join(HERE, src)] + hdrs):
                 jobs.append([HIPCC] + FLAGS + defs + ['-c', os.path.join(HERE, src), '-o', obj])
+            elif verbose:
+                print(f'[build] reused {os.path.relpath(obj, REPO)} (newer than its sources)', flush=True)
         links.append((lib, objs))
 
     def run(cmd):
         if verbose:
-            print('[build]', ' '.join(cmd[-3:]), flush=True)
+            print('[build] compiling / linking:', ' '.join(os.path.relpath(c, REPO) if os.path.isabs(c) else c for c in cmd[-3:]), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed:\n' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
@@ -59,6 +61,10 @@ def build(force=False, verbose=True):
     for lib, objs in links:
         if jobs or force or _stale(lib, objs):
             run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+        elif verbose:
+            print(f'[build] reused {os.path.relpath(lib, REPO)}', flush=True)
+    if verbose:
+        print(f'[build] {len(jobs)} object(s) compiled, {len(VARIANTS) * len(sources()) - len(jobs)} reused', flush=True)
     return LIB
 
 

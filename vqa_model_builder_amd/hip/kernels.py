@@ -203,24 +203,32 @@ def _wgrad_slot():
 
 
 WGRAD_SUMSQ = None      # optional device fp32 scalar: every grouped weight-gradient launch adds the sum of squares of what it writes (FusedAdamW's
-                        # global-norm reduction rides in the GEMMs: optim.FusedAdamW.fuse_wgrad_norm); the covered outputs are noted in WGRAD_SUMSQ_COVERED
-WGRAD_SUMSQ_COVERED = None
+                        # global-norm reduction rides in the GEMMs: optim.FusedAdamW.fuse_wgrad_norm); the covered address ranges are noted in
+WGRAD_SUMSQ_COVERED = None      # this list [(first byte, end byte)] since the optimiser's last zero_grad()
 
 
 def _launch_group(pending):
     global _group_items
     if _group_items is None:
         _group_items = (_l.VqaGemmGroupItem * WGRAD_GROUP_MAX)()
-    for i0 in range(0, len(pending), WGRAD_GROUP_MAX):
-        chunk = pending[i0:i0 + WGRAD_GROUP_MAX]
-        for it, a in zip(_group_items, chunk):
-            dy, x, M, N, Kd, ldy, ldx, out, _ = a
-            # dW[N,K] = dy[M,N]^T x[M,K]: GEMM rows = N, columns = K, reduction over the M tokens
-            it.a, it.b, it.c_f32 = _p(dy), _p(x), _p(out)
-            it.M, it.N, it.K, it.lda, it.ldb, it.ldc = N, Kd, M, ldy, ldx, out.stride(0)
-            if WGRAD_SUMSQ_COVERED is not None:
-                WGRAD_SUMSQ_COVERED.add((out.data_ptr(), N * Kd if out.stride(0) == Kd else -1))
-        _chk(L().vqa_gemm_bf16_grouped2(_group_items, len(chunk), 0, 0, _p(WGRAD_SUMSQ), _stream()), 'vqa_gemm_bf16_grouped2')
+    # outputs the optimiser can match against a parameter gradient by address range (contiguous [N, K] blocks) carry their sum of squares;
+    # anything else (a strided slot) goes in a call of its own without it, so that nothing is ever counted that the optimiser cannot see
+    fused = WGRAD_SUMSQ is not None and WGRAD_SUMSQ_COVERED is not None
+    groups = [(pending, None)]
+    if fused:
+        ok = [a for a in pending if a[7].is_contiguous()]
+        groups = [(ok, WGRAD_SUMSQ), ([a for a in pending if not a[7].is_contiguous()], None)]
+    for todo, ssq in groups:
+        for i0 in range(0, len(todo), WGRAD_GROUP_MAX):
+            chunk = todo[i0:i0 + WGRAD_GROUP_MAX]
+            for it, a in zip(_group_items, chunk):
+                dy, x, M, N, Kd, ldy, ldx, out, _ = a
+                # dW[N,K] = dy[M,N]^T x[M,K]: GEMM rows = N, columns = K, reduction over the M tokens
+                it.a, it.b, it.c_f32 = _p(dy), _p(x), _p(out)
+                it.M, it.N, it.K, it.lda, it.ldb, it.ldc = N, Kd, M, ldy, ldx, out.stride(0)
+                if ssq is not None:
+                    WGRAD_SUMSQ_COVERED.append((out.data_ptr(), out.data_ptr() + 4 * N * Kd))
+            _chk(L().vqa_gemm_bf16_grouped2(_group_items, len(chunk), 0, 0, _p(ssq), _stream()), 'vqa_gemm_bf16_grouped2')
 
 
 def wgrad_flush():

@@ -42,9 +42,53 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper_gi, self._hyper_lr, self._hyper_of = [], [], {}      # class -> group index, the lr last written to it, id(parameter) -> class
         self._hyper_key, self._epoch = [], 0              # class -> (group, step count at creation, step() call that created it)
         self._staging = {}                                # HIP-graph mode: pinned host rows per job table
+        self._wnorm2 = None                               # fuse_wgrad_norm(): device scalar the weight-gradient GEMMs add their sum of squares to
         self.grad_prescale = 1.0                          # DP: gradients hold the all-reduced SUM; 1/world is applied here
         self.wire_grads = None                            # DP captured step with bf16 buckets: id(parameter) -> device address of its all-reduced
                                                           # bfloat16 gradient in the exchange's staging buffer (read there: no copy back to fp32)
+
+    def fuse_wgrad_norm(self, on: bool = True, device=None):
+        """The global-norm reduction of ``clip_grad_norm_`` for the WEIGHT gradients rides in the grouped GEMMs that produce them (their epilogues
+        add the sum of squares of what they store to a device scalar: csrc/gemm_dw256.h, gemm_epilogue), instead of a pass that re-reads 4 B per
+        parameter: 0.98 GB per cfg2 step.  ``zero_grad()`` clears the scalar and the list of covered address ranges; ``step()`` leaves the covered
+        gradients out of its own norm pass and adds the scalar -- but only when every covered byte IS the gradient of a parameter it updates
+        (a tied weight whose two gradients autograd summed, a gradient a hook replaced, a second backward accumulated into the first: the
+        covered ranges and the gradients no longer coincide and the step falls back to the full pass, which is always correct).  One optimiser
+        at a time (the scalar hangs off hip.kernels); not for gradients that are all-reduced after the GEMMs (data parallel: the norm must be
+        the reduced gradients').  ``GraphedTrainStep`` switches it on for its single-GPU step."""
+        if on:
+            dev = torch.device(device) if device is not None else next((p.device for g in self.param_groups for p in g['params']), None)
+            self._wnorm2 = torch.zeros(1, dtype=torch.float32, device=dev)
+            K.WGRAD_SUMSQ, K.WGRAD_SUMSQ_COVERED = self._wnorm2, []
+        else:
+            if K.WGRAD_SUMSQ is self._wnorm2:
+                K.WGRAD_SUMSQ, K.WGRAD_SUMSQ_COVERED = None, None
+            self._wnorm2 = None
+        return self
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none)
+        if self._wnorm2 is not None and K.WGRAD_SUMSQ is self._wnorm2:
+            self._wnorm2.zero_()
+            K.WGRAD_SUMSQ_COVERED.clear()
+
+    def _norm_counted(self, grads):
+        """{id(parameter)} whose gradient lies inside an address range the weight-gradient GEMMs already took the sum of squares of, or None when
+        the covered ranges and the gradients do not coincide byte for byte (then the scalar is ignored).  ``grads``: [(id, first byte, end byte)]."""
+        if self._wnorm2 is None or K.WGRAD_SUMSQ is not self._wnorm2 or not K.WGRAD_SUMSQ_COVERED:
+            return None
+        import bisect
+        spans = sorted(set(K.WGRAD_SUMSQ_COVERED))
+        if len(spans) != len(K.WGRAD_SUMSQ_COVERED) or any(a[1] > b[0] for a, b in zip(spans, spans[1:])):
+            return None                                    # a range written twice (two backward passes since zero_grad) or overlapping ranges
+        starts = [a for a, _ in spans]
+        counted, nbytes = set(), 0
+        for pid, a, e in grads:
+            i = bisect.bisect_right(starts, a) - 1
+            if i >= 0 and e <= spans[i][1]:
+                counted.add(pid)
+                nbytes += e - a
+        return counted if nbytes == sum(e - a for a, e in spans) else None
 
     def attach_shadows(self, model):
         """Lets the update kernel write the bf16 / packed-fp32 weight shadows of the block runners directly."""
@@ -179,6 +223,7 @@ class FusedAdamW(torch.optim.Optimizer):
         launches, dev = {}, None                        # (group index, step count) -> rows: torch's bias correction is per-parameter
         counted = {}                                    # MoE layers under dense dispatch: id(steps) -> (active [E], steps [E], {expert: step so far})
         standalone = []
+        spans = []                                      # (id(parameter), first byte, end byte) of every fp32 gradient read where autograd left it
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
                 g = p.grad
@@ -201,6 +246,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     gptr, wire_flag = wire, 0x100           # VQA_OPT_GRAD_BF16
                 else:
                     wire_flag = 0
+                    spans.append((id(p), gptr, gptr + 4 * p.numel()))
                 updated.add(id(p))
                 if sp == 0:                                 # stand-alone parameter (tail ops, experts): its cached bf16 copy, if any
                     sh = _ops.standalone_shadow(p)
@@ -218,7 +264,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     ent[2].setdefault(e, prev_step)
                 launches.setdefault((gi, state['step']) if self._hyper is None else (gi, -1 - self._class_of(gi, p)), []).append(
                     (p.data_ptr(), gptr, state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
-                     act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0))
+                     act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0, id(p)))
                 dev = p.device
         if not launches:
             return loss
@@ -226,34 +272,46 @@ class FusedAdamW(torch.optim.Optimizer):
             self._norm2 = torch.zeros(1, dtype=torch.float32, device=dev)
         tables = []
         live = set()
-        for (gi, step), rows in launches.items():
-            key = tuple(rows)
+        # weight gradients whose sum of squares the GEMMs that wrote them have already taken (fuse_wgrad_norm): left out of the norm pass below
+        in_gemm = None if self.wire_grads else self._norm_counted(spans)
+        for (gi, step), rows9 in launches.items():
+            rows = [r[:9] for r in rows9]
+            flags = tuple(in_gemm is not None and r[9] in in_gemm for r in rows9)
+            key = (tuple(rows), flags)
             slot = (gi, len(tables))
             live.add(slot)
             cached = self._tables.get(slot)
             if cached is None or cached[0] != key:
                 ch = lib.vqa_opt_chunk_elems()
                 chunks = [(ji, off) for ji, r in enumerate(rows) for off in range(0, r[5], ch)]
+                nrm = [c for c in chunks if not flags[c[0]]]
                 stage = self._staging.get(slot)
-                if stage is not None and cached is not None and stage.shape[0] == len(rows) and cached[3] == len(chunks):
+                if stage is not None and cached is not None and stage.shape[0] == len(rows) and cached[3] == len(chunks) and cached[0][1] == flags:
                     # HIP-graph mode: same tensors, new addresses (gradients allocated from the graph's pool).  No
                     # allocation is legal inside a stream capture: refill the pre-pinned staging rows and copy them
                     # over the existing device table (a memcpy node that replays harmlessly).
                     stage.copy_(torch.tensor(rows, dtype=torch.int64))
                     cached[1].copy_(stage, non_blocking=True)
-                    cached = (key, cached[1], cached[2], cached[3])
+                    cached = (key,) + tuple(cached[1:])
                 else:
-                    cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks))
+                    cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(chunks, dtype=torch.int32).to(dev), len(chunks),
+                              torch.tensor(nrm, dtype=torch.int32).to(dev) if nrm and len(nrm) < len(chunks) else None, len(nrm))
                 self._tables[slot] = cached
-            tables.append((self.param_groups[gi], step, cached[1], cached[2], cached[3], gi))
+            tables.append((self.param_groups[gi], step, cached[1], cached[2], cached[3], gi, cached[4], cached[5]))
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         amp = None
         if self._amp_cfg is not None:
             amp = self._amp_state(dev)
         if clip or amp is not None:
-            self._norm2.zero_()
-            for _, _, tab, chunks, nch, _ in tables:
-                K._chk(lib.vqa_sumsq_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr(), st), 'vqa_sumsq_multi')
+            if in_gemm is not None:
+                self._norm2.copy_(self._wnorm2)            # the weight gradients' share, summed by the GEMMs that stored them
+            else:
+                self._norm2.zero_()
+            for _, _, tab, chunks, nch, _, nrm, nnrm in tables:
+                if nnrm == nch:
+                    K._chk(lib.vqa_sumsq_multi(tab.data_ptr(), chunks.data_ptr(), nch, self._norm2.data_ptr(), st), 'vqa_sumsq_multi')
+                elif nnrm > 0:
+                    K._chk(lib.vqa_sumsq_multi(tab.data_ptr(), nrm.data_ptr(), nnrm, self._norm2.data_ptr(), st), 'vqa_sumsq_multi')
         for a_all, s_all, first in counted.values():
             if not getattr(s_all, '_vqa_seeded', False):   # first sight (never inside a capture: the warm-up steps run eagerly): start
                 for e, n0 in first.items():                 # each expert's device count from what its parameters have received so far
@@ -261,7 +319,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 s_all._vqa_seeded = True
             K._chk(lib.vqa_opt_advance_counts(s_all.data_ptr(), a_all.data_ptr(), s_all.numel(), self._norm2.data_ptr() if amp is not None else None, st),
                    'vqa_opt_advance_counts')
-        for group, step, tab, chunks, nch, gi in tables:
+        for group, step, tab, chunks, nch, gi, _nrm, _nnrm in tables:
             b1, b2 = group['betas']
             hyper = None
             if self._hyper is not None:
