@@ -521,38 +521,45 @@ def main():
                                'bytes_per_step': byts, 'traffic': None,
                                'note': 'whole step against the batch-independent parameter traffic (4 + 4 + 30 B/param); activations excluded'}
 
-    # Data-parallel readiness, measured on ONE GPU: the segmented step (what N > 1 runs: one graph per block) without an exchange gives the
-    # compute side of an N-GPU step; the exchange of the last block (the only exposed one) is modelled from its byte count.
+    # Data-parallel readiness, measured on ONE GPU: the segmented step (what N > 1 runs: one graph per segment) without an exchange gives the
+    # compute side of an N-GPU step; each segment's exchange is modelled from its byte count on the exchange stream.  Run for the main
+    # workload AND for the MoE config (BASELINE configs[3] = cfg3 x 8 GPUs is what north_star's >= 6x is defined on: 477 M parameters, the
+    # MoE's 252 M of them produced first, in segment H), at three assumed bus bandwidths (no 8-GPU node has been measured yet).
     dp_model = None
     if world == 1 and not args.no_second_workload and not args.eager and not args.torch_optimizer:
-        try:
+        def model_for(workload, one_gpu_ms):
             args.force_segmented = True
-            seg = run_workload(args.workload, args, device, world, rank, dist, want_roofline=False)
-            args.force_segmented = False
-            BUS = 300e9                           # assumed all-reduce bus bandwidth of an 8-GPU xGMI node (7 links x ~153 GB/s per GPU, ~30 % of it)
+            try:
+                seg = run_workload(workload, args, device, world, rank, dist, want_roofline=False)
+            finally:
+                args.force_segmented = False
             sb, sm, sg = seg.get('segment_bytes', {}), seg.get('segment_ms', {}), seg.get('segment_gather_bytes_per_rank', {})
             total = seg['ms_per_step']
             t_opt = max(0.0, total - sum(sm.values()))
-            blocks = [k for k in sm if k != 'F']                 # in replay order: H, T, V (, V2)
+            blocks = [k for k in sm if k != 'F']                 # in replay order: H, B1 .. B4
 
-            def predict(wire):
-                # one RCCL stream: a block's exchange starts when its graph has finished AND the previous exchange is through
+            def predict(wire, bus):
+                # one RCCL stream: a segment's exchange starts when its graph has finished AND the previous exchange is through
                 ready, end = sm.get('F', 0.0), 0.0
                 for k in blocks:
                     ready += sm.get(k, 0.0)
                     dense = sb.get(k, 0) - sg.get(k, 0)              # measured at world 1: the gather part counted once
                     pack = (dense / 4) * 6 / 5.0e12 * 1e3 if wire < 1.0 else 0.0          # bf16 buckets: fp32 -> bf16 staging copy (4 B read + 2 B written per element, ~5 TB/s), on the exchange stream
-                    end = max(ready, end) + pack + (2 * (7 / 8) * dense * wire + 7 * sg.get(k, 0)) / BUS * 1e3      # ring all-reduce + all-gather of 8 ranks' rows
+                    end = max(ready, end) + pack + (2 * (7 / 8) * dense * wire + 7 * sg.get(k, 0)) / bus * 1e3      # ring all-reduce + all-gather of 8 ranks' rows
                 exposed = max(0.0, end - ready)
                 step = ready + exposed + t_opt
-                return {'exposed_allreduce_ms': round(exposed, 3), 'ms_per_step': round(step, 3), 'scaling_vs_1gpu': round(8 * main_res['ms_per_step'] / step, 2)}
-            dp_model = {'segmented_step_ms_1gpu': total, 'segment_ms_1gpu': sm, 'optimizer_ms': round(t_opt, 3), 'segment_bytes_fp32': sb,
-                        'assumed_bus_GBps': BUS / 1e9, 'predicted_8gpu_fp32_buckets': predict(1.0), 'predicted_8gpu_bf16_buckets': predict(0.5),
-                        'note': 'compute = the graphs of the segmented step measured on one GPU (no exchange); exchange = per segment, on the exchange stream: '
-                                '(bf16 buckets) the fp32 -> bf16 staging copy, then the ring all-reduce, started when the segment\'s graph is done and the previous '
-                                'segment\'s exchange is through; the optimiser reads the bf16 sums in place.  The xGMI bus bandwidth is an ASSUMPTION, not '
-                                'a measurement -- the driver\'s N = 8 run is the measurement.  Measured with a ONE-rank RCCL group (bench.py --force-dist): '
-                                'profiles/r02/rccl_one_rank_bench_*.log'}
+                return {'exposed_allreduce_ms': round(exposed, 3), 'ms_per_step': round(step, 3), 'scaling_vs_1gpu': round(8 * one_gpu_ms / step, 2)}
+            return {'one_graph_step_ms_1gpu': one_gpu_ms, 'segmented_step_ms_1gpu': total, 'segment_ms_1gpu': sm, 'optimizer_ms': round(t_opt, 3), 'segment_bytes_fp32': sb,
+                    'predicted_8gpu': {f'{int(bus / 1e9)}GBps': {'fp32_buckets': predict(1.0, bus), 'bf16_buckets': predict(0.5, bus)} for bus in (150e9, 300e9, 450e9)}}
+        try:
+            dp_model = {'note': 'compute = the graphs of the segmented step measured on one GPU (no exchange); exchange = per segment, on the exchange stream: (bf16 buckets) the '
+                                'fp32 -> bf16 staging copy, then the ring all-reduce, started when the segment\'s graph is done and the previous segment\'s exchange is through; the '
+                                'optimiser reads the bf16 sums in place.  The xGMI all-reduce bus bandwidth is an ASSUMPTION (three values; 7 links x ~153 GB/s per GPU is the '
+                                'hardware ceiling), not a measurement -- the driver\'s N = 8 run is the measurement.  RCCL itself has run with one rank (bench.py --force-dist, '
+                                'profiles/r03/rccl_one_rank_*.log; tests/test_dp_gpu.py).',
+                        args.workload: model_for(args.workload, main_res['ms_per_step'])}
+            if moe_res is not None and 'ms_per_step' in moe_res and args.workload != 'cfg3_mcan_moe4':
+                dp_model['cfg3_mcan_moe4'] = model_for('cfg3_mcan_moe4', moe_res['ms_per_step'])
         except Exception as e:                       # noqa: BLE001
             args.force_segmented = False
             dp_model = {'error': f'{type(e).__name__}: {e}'}

@@ -188,3 +188,96 @@ def test_overlap_hooks_world2_gloo():
             import numpy as np
             assert np.allclose(o0[i], want, atol=1e-6) and np.allclose(o1[i], want, atol=1e-6), (step, i)
         assert o0[-1] is None and o1[-1] is None
+
+
+def _wire_worker(rank, world, port, q):
+    """One of 8 ranks: the tiny model's REAL gradients of this rank's own batch (CPU oracle), laid out as the captured step lays them out (one flat
+    arena per block + a few stand-alone tensors), exchanged through GradReducer.prepare_static / reduce_static with fp32 and with bf16 buckets."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import det_weights as dw
+        from oracle import vqa_oracle as vo
+        from tests.conftest import CfgView, load_golden
+        from vqa_model_builder_amd.dp import GradReducer
+        arrays, meta = load_golden('tiny_mcan_moe4')
+        d = meta['dims']
+        sd = dw.make_state_dict({k: tuple(v) for k, v in meta['shapes'].items()}, meta['seed'])
+        px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=d['vocab'], num_answers=d['num_answers'], seed=500 + rank)
+        _, _, _, grads = vo.forward_backward(sd, CfgView(meta), px, ids, mask, labels, vit_heads=d['vit_heads'], text_heads=d['txt_heads'])
+        # every rank exchanges the SAME layout (the captured step runs the MoE densely: an expert no token of this rank chose has a zero gradient, not none)
+        names = list(meta['grad_names'])
+        grads = {n: (grads[n] if n in grads and grads[n] is not None else torch.zeros_like(sd[n])) for n in names}
+        results = {}
+        for wire in ('fp32', 'bf16'):
+            # arenas: every block (first three name components) holds its gradients in ONE flat buffer, as the block runners do; biases stand alone
+            blocks = {}
+            for n in names:
+                blocks.setdefault('.'.join(n.split('.')[:3]), []).append(n)
+            params = []
+            for key, members in blocks.items():
+                if len(members) == 1 or key.endswith('bias'):
+                    for n in members:
+                        p = torch.nn.Parameter(sd[n].clone())
+                        p.grad = grads[n].clone()
+                        params.append((n, p))
+                    continue
+                flat = torch.zeros(sum((grads[n].numel() + 3) // 4 * 4 for n in members))
+                off = 0
+                for n in members:
+                    p = torch.nn.Parameter(sd[n].clone())
+                    flat[off:off + grads[n].numel()].copy_(grads[n].reshape(-1))
+                    p.grad = flat[off:off + grads[n].numel()].view(grads[n].shape)
+                    off += (grads[n].numel() + 3) // 4 * 4
+                    params.append((n, p))
+            red = GradReducer([p for _, p in params], average=True, grad_dtype=wire)
+            red.prepare_static()
+            assert sum(len(s['flats']) for s in red._segments.values()) >= 2
+            red.reduce_static()
+            results[wire] = {n: p.grad.detach().clone() for n, p in params}
+        num = den = 0.0
+        worst = 0.0
+        for n in names:
+            a, b = results['bf16'][n].double(), results['fp32'][n].double()
+            num += float((a - b).norm() ** 2)
+            den += float(b.norm() ** 2)
+            if float(b.norm()) > 0:
+                worst = max(worst, float((a - b).norm() / b.norm()))
+        digest = float(sum(results['bf16'][n].double().sum() for n in names))
+        local_vs_mean = float(sum((grads[n].double() - results['fp32'][n].double()).norm() ** 2 for n in names) ** 0.5 / den ** 0.5)
+        q.put((rank, (num / den) ** 0.5, worst, digest, local_vs_mean))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_bf16_wire_sums_stay_inside_the_autocast_gradient_envelope():
+    """The N > 1 default of the captured step sends bfloat16 buckets and lets RCCL sum them in bf16 (dp.py prepare_static / reduce_segment): every
+    rank's gradient rounded to 8 bits once and seven bf16 additions on top.  Eight gloo ranks (what an 8-GPU node runs over RCCL), the tiny
+    MoE model's real gradients of eight different batches (CPU oracle), arenas + stand-alone tensors as in the captured step: against the fp32
+    exchange of the same gradients the bf16 exchange must stay well inside the error the REFERENCE's own bf16 autocast puts on these gradients
+    (the fixture's ``ac_bf16`` envelope), and all ranks must end up with bit-identical sums."""
+    import numpy as np
+    from tests.conftest import load_golden
+    arrays, meta = load_golden('tiny_mcan_moe4')
+    gn = np.array([float(arrays['gnorm/' + n]) for n in meta['grad_names']])
+    envelope = float(np.sqrt(((arrays['ac_bf16/gs'] * gn) ** 2).sum() / (gn ** 2).sum()))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_wire_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    from tests.helpers import collect_from_workers
+    res = sorted(collect_from_workers(q, procs, world, timeout=300))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    agg, worst, digest, spread = res[0][1], max(r[2] for r in res), res[0][3], res[0][4]
+    print(f'\nDP-WIRE 8 ranks: bf16-wire vs fp32 exchange aggregate rel-L2 {agg:.3e} (worst tensor {worst:.3e}); reference bf16-autocast envelope {envelope:.3e}; '
+          f'a rank\'s own gradient differs from the 8-rank mean by {spread:.2f} (the batches really differ)')
+    assert all(r[3] == digest for r in res), [r[3] for r in res]              # replicas stay identical
+    assert spread > 0.3                                                       # eight DIFFERENT gradients were summed
+    assert agg <= 0.5 * envelope, (agg, envelope)
+    assert worst <= 2e-2

@@ -63,6 +63,23 @@ def test_model_gradients_average_across_two_ranks():
         assert np.allclose(r0[n], want, rtol=1e-5, atol=1e-7), n
 
 
+def _full_cfg3(batch=4):
+    """BASELINE configs[2] / configs[3] at FULL size (ViT-B/32 + PhoBERT + 'mcan' fusion + MoE-4 @ 2048: 477 M parameters), weights drawn on the GPU
+    from a fixed seed (identical replicas on every rank; the reference-made fixtures pin the NUMBERS of this config elsewhere: test_parity_gpu)."""
+    from oracle import det_weights as dw
+    from oracle.gen_golden import FULL
+    from tests.helpers import build_model
+    torch.manual_seed(0)
+    model = build_model({'dims': FULL, 'fusion_type': 'mcan', 'num_experts': 4}).to('cuda:0').eval()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02, generator=g)
+    d = FULL
+    return model, d, batch
+
+
 def _train_worker(rank, world, port, q, mode):
     """Three data-parallel training steps (no dropout) either eagerly (hooks + finalize) or as forward+backward graph ->
     eager exchange -> optimiser graph (graph.GraphedTrainStep with a reducer): same losses, same parameters."""
@@ -76,19 +93,22 @@ def _train_worker(rank, world, port, q, mode):
         from vqa_model_builder_amd.dp import GradReducer
         from vqa_model_builder_amd.graph import GraphedTrainStep
         from vqa_model_builder_amd.optim import FusedAdamW
-        meta = {'dims': TINY, 'fusion_type': 'cross_attention', 'num_experts': 4 if mode.endswith('_moe') else 0}
-        model = build_model(meta)
-        model.load_state_dict(dw.make_state_dict(dw.shapes_of(model.state_dict()), 5))
-        model = model.to('cuda:0').eval()
+        if mode.endswith('_full'):
+            model, d, B = _full_cfg3()
+        else:
+            meta = {'dims': TINY, 'fusion_type': 'cross_attention', 'num_experts': 4 if mode.endswith('_moe') else 0}
+            model = build_model(meta)
+            model.load_state_dict(dw.make_state_dict(dw.shapes_of(model.state_dict()), 5))
+            model = model.to('cuda:0').eval()
+            d, B = TINY, TINY['batch']
         params = [p for p in model.parameters() if p.requires_grad]
-        opt = FusedAdamW(params, lr=2e-4, weight_decay=0.01, max_grad_norm=1.0).attach_shadows(model)
-        d = TINY
-        px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=d['vocab'], num_answers=d['num_answers'], seed=50 + rank)
+        opt = FusedAdamW(params, lr=2e-4 if not mode.endswith('_full') else 2e-5, weight_decay=0.01, max_grad_norm=1.0).attach_shadows(model)
+        px, ids, mask, labels = dw.make_inputs(B, d['seq'], d['image'], vocab_hi=min(30000, d['vocab']), num_answers=d['num_answers'], seed=50 + rank)
         batch = dict(pixel_values=px.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
-        losses, n, warm = [], 5, 2
+        losses, n, warm = [], (4 if mode.endswith('_full') else 5), 2
         info = {}
         if mode.startswith('eager'):
-            red = GradReducer(params, bucket_mb=0.5).attach()
+            red = GradReducer(params, bucket_mb=64.0 if mode.endswith('_full') else 0.5).attach()
             for _ in range(n):
                 opt.zero_grad(set_to_none=True)
                 out = model(**batch)
@@ -97,7 +117,7 @@ def _train_worker(rank, world, port, q, mode):
                 opt.step()
                 losses.append(out.loss.item())
         else:
-            red = GradReducer(params, bucket_mb=0.5, average=False,     # the SUM stays in memory, the optimiser applies 1/world
+            red = GradReducer(params, bucket_mb=64.0 if mode.endswith('_full') else 0.5, average=False,     # the SUM stays in memory, the optimiser applies 1/world
                               grad_dtype='bf16' if 'bf16' in mode else 'fp32')
             opt.grad_prescale = 1.0 / world
             gs = GraphedTrainStep(model, opt, batch, reducer=red, warmup=warm, capture_error_mode='thread_local',
@@ -114,7 +134,7 @@ def _train_worker(rank, world, port, q, mode):
         dist.destroy_process_group()
 
 
-def _run_two(mode):
+def _run_two(mode, timeout=120):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     with socket.socket() as s:
@@ -124,9 +144,9 @@ def _run_two(mode):
     for p in procs:
         p.start()
     from tests.helpers import collect_from_workers
-    res = {rank: (losses, sig, info) for rank, losses, sig, info in collect_from_workers(q, procs, 2)}
+    res = {rank: (losses, sig, info) for rank, losses, sig, info in collect_from_workers(q, procs, 2, timeout=timeout)}
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=timeout)
         assert p.exitcode == 0
     return res
 
@@ -170,6 +190,24 @@ def test_segmented_data_parallel_step_with_moe_dense_dispatch():
     assert abs(graph[0][1] - graph[1][1]) <= 1e-9 * graph[0][1]
 
 
+def test_full_size_cfg3_segmented_step_matches_eager_data_parallel_step_on_two_ranks():
+    """BASELINE configs[3] is configs[2] x data parallelism: the FULL-size MoE model (477 M parameters; batch 4 per rank) through the depth-segmented
+    captured step -- dense MoE dispatch inside the captures, routed-token counts all-reduced, bf16 buckets read on the wire by the optimiser, four
+    depth segments of both twelve-layer towers, sparse embedding rows -- on two ranks (gloo on one device), against the eager data-parallel step with
+    hook-overlapped fp32 buckets: same loss trajectory, same parameters to bf16-exchange rounding, identical replicas."""
+    eager, graph = _run_two('eager_moe_full', timeout=600), _run_two('graph_bf16_moe_full', timeout=600)
+    info = graph[0][2]
+    assert info['segmented'] and set(info['stats']['segment_bytes']) == {'H', 'B1', 'B2', 'B3', 'B4'}, info
+    assert info['sparse'] == 1 and info['wired'] > 300, info
+    print('\nDP-FULL cfg3 two ranks: segment MB', {k: round(v / 1e6, 1) for k, v in info['stats']['segment_bytes'].items()}, 'segment ms', info['stats'].get('segment_ms'),
+          'losses eager', eager[0][0], 'graph', graph[0][0])
+    for r in (0, 1):
+        for a, b in zip(eager[r][0][2:], graph[r][0][2:]):
+            assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (r, eager[r][0], graph[r][0])
+        assert abs(eager[r][1] - graph[r][1]) <= 1e-4 * eager[r][1], (eager[r][1], graph[r][1])
+    assert abs(graph[0][1] - graph[1][1]) <= 1e-9 * graph[0][1]
+
+
 def _rccl_worker(rank, world, port, q, wire):
     """ONE rank over the real RCCL backend ('nccl'): the seven-graph data-parallel step with every all-reduce / all-gather really issued
     (GradReducer(force_collectives=True)), against the plain one-graph step of the same model on the same batch."""
@@ -184,26 +222,34 @@ def _rccl_worker(rank, world, port, q, wire):
         from vqa_model_builder_amd.dp import GradReducer
         from vqa_model_builder_amd.graph import GraphedTrainStep
         from vqa_model_builder_amd.optim import FusedAdamW
-        d = TINY
-        px, ids, mask, labels = dw.make_inputs(d['batch'], d['seq'], d['image'], vocab_hi=d['vocab'], num_answers=d['num_answers'], seed=50)
+        full = wire.endswith('_full')
+        wire = wire.replace('_full', '')
+        d, B = (__import__('oracle.gen_golden', fromlist=['FULL']).FULL, 4) if full else (TINY, TINY['batch'])
+        px, ids, mask, labels = dw.make_inputs(B, d['seq'], d['image'], vocab_hi=min(30000, d['vocab']), num_answers=d['num_answers'], seed=50)
         batch = dict(pixel_values=px.cuda(), input_ids=ids.cuda(), attention_mask=mask.cuda(), labels=labels.cuda())
         res = {}
         for mode in ('plain', 'rccl'):
-            model = build_model({'dims': TINY, 'fusion_type': 'cross_attention', 'num_experts': 0})
-            model.load_state_dict(dw.make_state_dict(dw.shapes_of(model.state_dict()), 5))
-            model = model.to('cuda:0').eval()
+            if full:
+                model = _full_cfg3()[0]
+            else:
+                model = build_model({'dims': TINY, 'fusion_type': 'cross_attention', 'num_experts': 0})
+                model.load_state_dict(dw.make_state_dict(dw.shapes_of(model.state_dict()), 5))
+                model = model.to('cuda:0').eval()
             params = [p for p in model.parameters() if p.requires_grad]
-            opt = FusedAdamW(params, lr=2e-4, weight_decay=0.01, max_grad_norm=1.0).attach_shadows(model)
+            opt = FusedAdamW(params, lr=2e-5 if full else 2e-4, weight_decay=0.01, max_grad_norm=1.0).attach_shadows(model)
             red = None
             if mode == 'rccl':
-                red = GradReducer(params, bucket_mb=0.5, average=False, grad_dtype=wire, force_collectives=True)
+                red = GradReducer(params, bucket_mb=64.0 if full else 0.5, average=False, grad_dtype=wire, force_collectives=True)
                 assert not red.single
             gs = GraphedTrainStep(model, opt, batch, reducer=red, warmup=2, capture_error_mode='thread_local')
             losses = [gs(batch).item() for _ in range(3)]
             torch.cuda.synchronize()
             info = dict(segmented=gs.segmented, stats=gs.comm_stats() if red is not None else {}, backend=dist.get_backend())
             res[mode] = (losses, float(sum(p.detach().double().abs().sum().item() for p in params)), info)
-            del gs, opt, model
+            del gs, opt, model, red, params
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
         t = torch.ones(4, device='cuda')
         dist.all_reduce(t)
         dist.barrier()
@@ -212,7 +258,7 @@ def _rccl_worker(rank, world, port, q, wire):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('wire,tol', [('fp32', 1e-5), ('bf16', 2e-3)])
+@pytest.mark.parametrize('wire,tol', [('fp32', 1e-5), ('bf16', 2e-3), ('bf16_full', 2e-3)])
 def test_segmented_step_over_one_rank_rccl(wire, tol):
     """RCCL itself (torch.distributed backend 'nccl') on the one GPU a box has: communicator set-up, in-place all-reduce of the gradient arenas
     on RCCL's stream beside the next graph's replay, the bf16 wire copies, the all-gather of the embedding rows.  With one rank every sum is the
@@ -225,11 +271,13 @@ def test_segmented_step_over_one_rank_rccl(wire, tol):
     procs = [ctx.Process(target=_rccl_worker, args=(0, 1, port, q, wire))]
     procs[0].start()
     from tests.helpers import collect_from_workers
-    (_, res, ones), = collect_from_workers(q, procs, 1)
-    procs[0].join(timeout=120)
+    (_, res, ones), = collect_from_workers(q, procs, 1, timeout=600)
+    procs[0].join(timeout=600)
     assert procs[0].exitcode == 0
     assert ones == [1.0] * 4 and res['rccl'][2]['backend'] == 'nccl'
-    assert res['rccl'][2]['segmented'] and set(res['rccl'][2]['stats']['segment_bytes']) == {'H', 'B1', 'B2'}
+    # 'bf16_full': BASELINE configs[2] at full size (477 M parameters, MoE-4 densely dispatched inside the captures, four depth segments)
+    segs = {'H', 'B1', 'B2', 'B3', 'B4'} if wire.endswith('_full') else {'H', 'B1', 'B2'}
+    assert res['rccl'][2]['segmented'] and set(res['rccl'][2]['stats']['segment_bytes']) == segs
     for a, b in zip(res['plain'][0], res['rccl'][0]):
         assert abs(a - b) <= max(tol, 1e-5) * max(1.0, abs(a)), res
     assert abs(res['plain'][1] - res['rccl'][1]) <= max(tol, 1e-6) * res['plain'][1], res

@@ -44,26 +44,29 @@ def test_weight_gradient_norm_taken_in_the_gemms_equals_the_norm_pass():
     gradient -- with and without MoE experts (stand-alone parameters), and a second backward accumulated into the first (the covered ranges no
     longer ARE the gradients) must fall back to the full pass instead of clipping against a stale norm."""
     for setup in (_setup, _moe_setup):
-        res = []
+        first = []
         for fused in (False, True):
             model, opt, batch = setup(False) if setup is _setup else setup()
             if fused:
                 opt.fuse_wgrad_norm(True)
             try:
-                norms = []
-                for _ in range(3):
+                for step in range(3):
                     opt.zero_grad(set_to_none=True)
                     model(**batch).loss.backward()
+                    # the norm torch would clip against, from the very gradients this step consumes (independent of how the run got here:
+                    # the tiny model's trajectory amplifies a 1e-7 difference in the clip coefficient ~1000x per step)
+                    want = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
                     opt.step()
-                    norms.append(float(opt.grad_norm()))
-                res.append((norms, [p.detach().clone() for p in model.parameters()], opt))
+                    got = float(opt.grad_norm())
+                    assert abs(got - want) <= 1e-5 * want, (fused, step, got, want)
+                    if step == 0:
+                        first.append((got, [p.detach().clone() for p in model.parameters()]))
             finally:
                 opt.fuse_wgrad_norm(False)
-        (n0, p0, _), (n1, p1, o1) = res
-        for a, b in zip(n0, n1):
-            assert abs(a - b) <= 2e-5 * a, (n0, n1)
+        (n0, p0), (n1, p1) = first
+        assert abs(n0 - n1) <= 2e-6 * n0, (n0, n1)          # same gradients in both runs at the first step: same norm, same update
         for a, b in zip(p0, p1):
-            assert torch.allclose(a, b, atol=2e-6, rtol=1e-4)
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
     # accumulation of two backward passes: the fused bookkeeping must notice and the norm must be that of the SUMMED gradients
     model, opt, batch = _setup(False)
     ref_model, ref_opt, _ = _setup(False)

@@ -20,7 +20,8 @@ Tolerances come FROM THE REFERENCE, not from us.  Each fixture stores what the r
                       select_samples): the test asserts that no sample of those falls inside the tie band;
   * gradients         norm-weighted aggregate rel-L2 error of the fixture's samples <= ENV x the same aggregate of the reference's
                       autocast run on the batch-32 fixtures, 2 x on the tiny / batch-8 ones (no absolute floor; see ENV_GRAD_SMALL);
-                      every tensor's norm within max(15 %, ENV x the reference's own change);
+                      every tensor's norm within max(15 %, ENV^2 x the reference's own change) (the norm of a noisy vector grows with the SQUARE of
+                      its noise ratio: see _run_case);
                       the five worst tensors are printed next to the reference's figure for them.
 Per-kernel numerics (tests/test_kernels_gpu.py) are checked separately against fp32 torch (and EXACTLY for the GEMM layouts);
 teacher-forced per-block gradients (<= 4e-2 per tensor) in tests/test_blocks_gpu.py.
@@ -167,9 +168,14 @@ def _run_case(tag, rich, mode, with_oracle, gate_gradients=True):
             num += (es * ref_n) ** 2
             env_num += (ref_samp[name] * ref_n) ** 2
             den += ref_n ** 2
-            report.setdefault('gnorm_errs', {})[name] = (en, max(NORM_TOL, ENV * ref_full[name]))
+            # the NORM of a gradient carrying noise of relative size rho is biased upward by ~rho^2 / 2: quadratic in the noise ratio.  "Noise within
+            # ENV x the reference's own" therefore bounds the norm change by ENV^2 x the reference's own norm change (round 2 used ENV x: too tight
+            # by a factor ENV exactly for the noise-dominated tensors -- the MoE router gate, whose gradient is 40 - 55 % noise in bf16 for the
+            # reference's autocast and for this path alike)
+            norm_tol = max(NORM_TOL, ENV * ENV * ref_full[name])
+            report.setdefault('gnorm_errs', {})[name] = (en, norm_tol)
             if gate_gradients:
-                assert en <= max(NORM_TOL, ENV * ref_full[name]), (tag, name, 'gradient norm', en, ref_full[name])
+                assert en <= norm_tol, (tag, name, 'gradient norm', en, ref_full[name])
         report['grad_global_rel_l2'] = float(np.sqrt(num / den))
         report['ref_autocast_grad_global'] = float(np.sqrt(env_num / den))
         report['gnorm_worst_rel'] = worst_n
