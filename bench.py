@@ -479,7 +479,7 @@ def main():
         # (gemm_v1* / gemm_kernel / gemm_ws ring and register-staged GEMMs, the grouped launches, the fused in-projection + attention
         # and cross-attention block kernels) -- recomputable by hand from the committed CSV.
         rocprof = None
-        FAMILY = ('gemm_v1', 'gemm_kernel', 'gemm_ws', 'gemm_grp', 'fused_inproj_attn_kernel', 'xattn_block')
+        FAMILY = ('gemm_v1', 'gemm_kernel', 'gemm_ws', 'gemm_grp', 'gemm_dw256', 'fused_inproj_attn_kernel', 'xattn_block')
         for rnd in ('r03', 'r02'):
             try:
                 import csv
