@@ -792,14 +792,19 @@ template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, boo
 __global__ __launch_bounds__(WM_ * WN_ * 64) __attribute__((amdgpu_waves_per_eu(ring_waves_per_simd(STAGES1 * (BM + BN) * BKT * 2, WM_ * WN_))))
 void gemm_v1_kernel(const GemmArgs p) {
     const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
-    // PERSISTENT when the host capped the grid (vqa_set_gemm_grid_cap): workgroup b walks tiles b, b + G, b + 2G ...  A capped
-    // grid leaves LDS / wave slots on every CU for the kernels of an independent launch chain (the other encoder's
-    // branch of the captured graph), so the two chains really run side by side instead of one filling the other's tails.
-    // G is a multiple of 8, so a workgroup's tiles stay on its XCD's contiguous range of the remap.
+#ifdef VQA_GEMM_PERSIST     // A/B builds only (scratch/ab_build.sh): the rounds-1/2 form
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, xcd_remap(t, ntiles));
-        __syncthreads();                                     // the ring (epilogue scratch) is free again
+        __syncthreads();
     }
+#else
+    // ONE tile per workgroup, no loop.  Through round 2 this was a persistent loop `for (t = blockIdx.x; t < ntiles; t += gridDim.x)` for a grid
+    // cap that measured slower and was never switched on -- and the loop cost every launch: everything loop-invariant in the body (the epilogue's
+    // ~40 argument words, its flag tests, the dropout / GELU constants, 60 SGPR spills into VGPR lanes) was hoisted by LICM into the loop
+    // pre-header, i.e. IN FRONT of the first global_load_lds the body so carefully issues first: ~290 instructions and six kernarg round trips
+    // before the ring was primed (ISA of round 3).
+    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, xcd_remap(blockIdx.x, ntiles));
+#endif
 }
 
 // GROUPED launch: up to MAX_GROUP independent fp32-output GEMMs of one operand layout in ONE grid (the weight-gradient GEMMs
@@ -1078,7 +1083,9 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
     }
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int grid = tiles;
+#ifdef VQA_GEMM_PERSIST
     if (g_grid_cap > 0 && splits == 1 && tiles > g_grid_cap) grid = g_grid_cap / 8 * 8;
+#endif
     vqa_launch(kern, dim3(grid, 1, splits), dim3(WM_ * WN_ * 64), LDS, st, p, 2.0 * p.M * p.N * p.K, gemm_alg_bytes(p));
     return (int)hipGetLastError();
 }
