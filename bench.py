@@ -367,7 +367,6 @@ def main():
     ap.add_argument('--tail-runner', type=int, default=None, help='diagnostics: 0 = projection / norm / dropout / answer head as op-by-op chain instead of one node')
     ap.add_argument('--expert-runners', type=int, default=None, help='diagnostics: 0 = MoE experts as op-by-op chains (hip/ops.py) instead of the runners')
     ap.add_argument('--moe-branches', type=int, default=None, help='diagnostics: MoE experts on side streams in the captured step (0 off, 1 specialised experts, 2 every expert)')
-    ap.add_argument('--group-persistent', type=int, default=None, help='diagnostics: vqa_set_gemm_group_persistent (workgroups of the grouped weight-gradient launches)')
     ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the captured HIP graph of the step')
     ap.add_argument('--dp-split', default='depth', choices=['depth', 'towers'],
@@ -434,8 +433,6 @@ def main():
         _K1.TRAIN_K_ROTATE = args.gemm_k_rotate if args.gemm_k_rotate == 2 else bool(args.gemm_k_rotate)
     if args.gemm_ws is not None:
         lib.load().vqa_set_gemm_ws(args.gemm_ws)
-    if args.group_persistent is not None:
-        lib.load().vqa_set_gemm_group_persistent(args.group_persistent)
     if args.fused_attn is not None:
         from vqa_model_builder_amd.hip import kernels as _K
         _K.FUSED_ATTENTION_FUSION, _K.FUSED_ATTENTION_ENCODERS = bool(args.fused_attn & 1), bool(args.fused_attn & 2)

@@ -90,14 +90,13 @@ int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches)
 /* the same, plus per tag the launches' ALGORITHMIC bytes: both operands once + every output / fused epilogue stream once (bytes may be NULL) */
 int vqa_gemm_profile_collect2(int ntags, double* flop, double* ms, int* launches, double* bytes);
 void vqa_set_gemm_ws(int mode);           /* one-tile-per-CU loader/consumer GEMM (csrc/gemm.hip: gemm_ws): 0 off (default: slower inside the step, profiles/r02/gemm_ws.md), 1 auto, 2 + i: force its tile i, 0x100 * mask + ...: auto over the masked tiles */
-void vqa_set_gemm_grid_cap(int cap);      /* > 0: LDS-DMA GEMMs run persistent on at most `cap` workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_force(int cfg, int stages);   /* diagnostics: tile id (0: 128x128, 1: 64x64, 4: 128x64, 5: 64x128; -1: heuristics) for every LDS-DMA launch */
 void vqa_set_gemm_tile_order(int order);         /* 0 / 1 (default): row-major tile ids; 2: column-major (an XCD owns output columns: every weight line fetched by ONE XCD) -- lab */
 void vqa_set_gemm_k_rotate(int on);             /* low byte 1: workgroups of XCD x start their k loop x/8 of the way through K (one HBM fetch per weight line instead of eight concurrent misses); 2: the grouped launches too;
                                                  * bits 8..10: a phase added to x (another assignment of starting points = another fp32 summation order: tests) */
-void vqa_set_gemm_group_persistent(int n); /* > 0: grouped launches run persistent on at most n workgroups (0: one workgroup per tile) */
 void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
+void vqa_set_gemm_v1_fast(int on);         /* 1 (default): ring GEMMs on whole tiles (K % 64 == 0, no split-K) run the compact-prologue instantiation; 0: the general form only (tests, A/B) */
 void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */
 
 /* ---- elementwise / layout --------------------------------------------------------------------------------- */

@@ -15,3 +15,5 @@ extern "C" int lab_gemm(const void* a, const void* b, void* c_bf16, float* c_f32
     p.k_per_split = (K + LAB_BK - 1) / LAB_BK * LAB_BK;
     return launch_v1s<LAB_BM, LAB_BN, LAB_WM, LAB_WN, LAB_BK, LAB_ST>(p, a_kc, b_kc, 1, (hipStream_t)stream);
 }
+
+extern "C" void lab_set_fast(int on) { g_v1_fast = on != 0; }

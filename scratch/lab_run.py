@@ -1,7 +1,9 @@
 """Runs one scratch/lab_*.so GEMM instance and prints its in-kernel timeline (s_memtime stamps per workgroup).
 usage: lab_run.py LIB LAY M N K [GROUP_M]"""
 import sys, ctypes as C, numpy as np, torch
+import os
 lib = C.CDLL(sys.argv[1]); lay = sys.argv[2]
+if os.environ.get('LAB_FAST') == '0': lib.lab_set_fast(0)          # the general-form instantiation
 M, N, Kd = [int(x) for x in sys.argv[3:6]]
 gm = int(sys.argv[6]) if len(sys.argv) > 6 else 8
 vp = C.c_void_p
@@ -28,7 +30,7 @@ us = e0.elapsed_time(e1) / 20 * 1e3
 af, bf = a.float(), b.float()
 ref = (af if lay != 'TN' else af.t()) @ (bf.t() if lay == 'NT' else bf)
 got = outb.float() if lay != 'TN' else outf
-print(f'{sys.argv[1]} {lay} {M}x{N}x{Kd}: {us:.1f} us/launch  {2.0 * M * N * Kd / us / 1e6:.0f} TF   rel err {((got - ref).norm() / ref.norm()).item():.2e}')
+print(f'{sys.argv[1]} fast={os.environ.get("LAB_FAST", "1")} {lay} {M}x{N}x{Kd}: {us:.1f} us/launch  {2.0 * M * N * Kd / us / 1e6:.0f} TF   rel err {((got - ref).norm() / ref.norm()).item():.2e}')
 run(trace.data_ptr()); torch.cuda.synchronize()
 t = trace.cpu().numpy().astype(np.int64)
 t = t[t[:, 0] != 0]
@@ -42,6 +44,7 @@ print(f'workgroups {nwg}, traced k-steps {nst}, kernel span {span} ticks')
 def stat(x): return f'min {x.min():7d} p50 {int(np.median(x)):7d} p90 {int(np.percentile(x, 90)):7d} max {x.max():7d}'
 print('start offset      ', stat(t[:, 0] - t0))
 print('init+prologue     ', stat(t[:, 1] - t[:, 0]))
+print('  of it: dma_init  ', stat(t[:, 31] - t[:, 0]))
 print('first tile landed ', stat(t[:, 2] - t[:, 1]))
 if nst > 1:
     d = np.stack([steps[i + 1][1] - steps[i][1] for i in range(nst - 1)], 1)

@@ -1080,3 +1080,52 @@ def test_gemm_k_rotation_is_exact_on_integer_data_and_only_reorders_the_sum():
     finally:
         L.vqa_set_gemm_k_rotate(0)
         K._k_rotate_state = None
+
+
+def test_compact_prologue_ring_kernels_equal_the_general_form_bit_for_bit():
+    """The FAST instantiations of the ring GEMM (csrc/gemm.hip: gemm_v1_body<..., FAST>: whole tiles, K % 64 == 0, no split-K -- bare base
+    pointers + a k-tile index instead of per-lane step / limit descriptors) walk the SAME k tiles in the SAME order as the general form they are
+    chosen over: outputs must be identical to the bit on real-valued data -- every layout, the 32x32 / 64x64 / 128x64 tiles, k rotation off and
+    on (three phases), fused epilogue options (bias + GELU + saved pre-activation; act' * dropout + residual + column sums) -- and equal to the
+    exact product on integer-valued data."""
+    L = hl.load()
+    g = torch.Generator().manual_seed(3)
+
+    def real(shape, s=1.0):
+        return (torch.randn(shape, generator=g) * s).to(DEV)
+    try:
+        for (M, N, Kd) in [(2048, 768, 3072), (1600, 768, 768), (2048, 3072, 768), (1600, 2304, 768), (128, 2048, 4096), (64, 512, 768), (512, 768, 1024)]:
+            for a_kc, b_kc in [(True, True), (True, False), (False, False), (False, True)]:
+                a = real((M, Kd) if a_kc else (Kd, M)).to(BF)
+                b = real((N, Kd) if b_kc else (Kd, N), 1.0 / math.sqrt(Kd)).to(BF)
+                bias, res = real((N,)), real((M, N))
+                z = real((M, N)).to(BF)
+                for rot in (0, 1, 1 | (5 << 8)):
+                    L.vqa_set_gemm_k_rotate(rot)
+                    outs = []
+                    for fast in (1, 0):
+                        L.vqa_set_gemm_v1_fast(fast)
+                        o1, ob, pre = torch.zeros((M, N), device=DEV), torch.zeros((M, N), device=DEV, dtype=BF), torch.zeros((M, N), device=DEV, dtype=BF)
+                        K.gemm(a, b, M, N, Kd, Kd if a_kc else M, Kd if b_kc else N, a_kc, b_kc, out_f32=o1, out_bf16=ob, pre_bf16=pre, bias=bias, act=K.ACT_GELU)
+                        o2, cs = torch.zeros((M, N), device=DEV), torch.zeros((N,), device=DEV)
+                        K.gemm(a, b, M, N, Kd, Kd if a_kc else M, Kd if b_kc else N, a_kc, b_kc, out_f32=o2, residual=res, act_grad_of=z, act_bwd=K.ACT_GELU,
+                               drop=K.Drop(0.1, 1234, 7), colsum=cs)
+                        outs.append((o1, ob, pre, o2, cs))
+                    for x, y in zip(outs[0][:4], outs[1][:4]):
+                        assert torch.equal(x, y), (M, N, Kd, a_kc, b_kc, rot)
+                    assert torch.allclose(outs[0][4], outs[1][4], rtol=1e-4, atol=1e-3)      # column sums: fp32 atomics, order not fixed
+        gi = torch.Generator().manual_seed(0)
+        for (M, N, Kd) in [(2048, 768, 3072), (1600, 768, 768), (256, 128, 512)]:
+            a = torch.randint(-3, 4, (M, Kd), generator=gi).float().to(DEV)
+            b = torch.randint(-3, 4, (N, Kd), generator=gi).float().to(DEV)
+            for fast in (1, 0):
+                L.vqa_set_gemm_v1_fast(fast)
+                for rot in (0, 1):
+                    L.vqa_set_gemm_k_rotate(rot)
+                    o = torch.zeros((M, N), device=DEV)
+                    K.gemm(a.to(BF), b.t().contiguous().to(BF), M, N, Kd, Kd, N, True, False, out_f32=o)
+                    assert torch.equal(o, a @ b.t()), (M, N, Kd, fast, rot)
+    finally:
+        L.vqa_set_gemm_v1_fast(1)
+        L.vqa_set_gemm_k_rotate(0)
+        K._k_rotate_state = None

@@ -194,14 +194,16 @@ __device__ __forceinline__ h16x8 load_frag(const char* lds, int r0, int s, int l
 // chunk(b % 8) + b / 8 and every XCD (private 4-MiB L2) works on one contiguous, row-major range of tile ids.  (Walking that
 // range in groups of tile-rows measured 2 % slower inside the training step than plain row-major order and was removed.)
 __device__ __forceinline__ int xcd_remap(int t, int ntiles) {
-    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective
+    const unsigned q = (unsigned)ntiles >> 3, r = (unsigned)ntiles & 7u, xcd = (unsigned)t & 7u, idx = (unsigned)t >> 3;
+    return (int)(xcd * q + min(xcd, r) + idx);           // bijective: XCD x owns q (+ 1 for x < r) consecutive tile ids; branch-free
 }
+// t -> (t / tiles_n, t % tiles_n) by one multiply: magic = ceil(2^31 / tiles_n) (div_magic; 2^31 itself for tiles_n = 1, so no special case and
+// no branch), quotient = high word of 2t * magic: exact while t * tiles_n < 2^31
 __device__ __forceinline__ void tile_from_linear(int tiles_n, unsigned magic, int t, int& tm, int& tn) {
-    tm = magic ? (int)__umulhi((unsigned)t, magic) : t;          // exact for t * tiles_n < 2^32 (host: magic = ceil(2^32 / tiles_n))
+    tm = (int)__umulhi((unsigned)t << 1, magic);
     tn = t - tm * tiles_n;
 }
-static inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+static inline unsigned div_magic(int d) { return d <= 1 ? 0x80000000u : (unsigned)((0x80000000ull + (unsigned)d - 1) / (unsigned)d); }
 template <int BM, int BN>
 __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
     const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
@@ -234,9 +236,9 @@ template <int TM, int TN> constexpr int epi_group(int avail, int nw) {
 // (The two forms are separate instantiations: with both in one body the compiler waits vmcnt(0) before the asm LDS read anyway -- it
 // overwrites the register the other path's global load may still be filling.)
 template <int TM, int TN> constexpr int epi_oper_bytes() { return (TM * 16 * TN * 16 * 4 + 1023) / 1024 * 1024; }     // sized for fp32
-template <int TM, int TN, int G, bool ODMA = false>
+template <int TM, int TN, int G, bool ODMA = false, bool NOSPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch, char* oper = nullptr) {
-    const bool splitk = gridDim.z > 1;
+    const bool splitk = !NOSPLIT && gridDim.z > 1;
     // dropout key: resolved here, at its only use (an INDIRECT seed costs one scalar load whose latency hides behind the stores);
     // resolving it at kernel entry by patching a copy of the argument struct put the struct in scratch memory and opened every
     // launch with a scratch store + load round trip
@@ -575,7 +577,14 @@ __device__ __forceinline__ void frag_fence(h16x8 (&fa)[NA], h16x8 (&fb)[NB]) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // WM_ x WN_ waves, each a (BM/WM_) x (BN/WN_) wave tile; BKT = 32 or 64 elements of k per ring stage.
-template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
+// FAST (host: K % BKT == 0, no split-K, every 16-B chunk of a row-contiguous operand inside its row): the k-tile index is all the state the ring's
+// refills carry.  Lane descriptors are bare base pointers; tile kk of an operand lies kk * (uniform byte step) behind them -- one scalar multiply per
+// operand and one v_lshl_add_u64 per DMA -- so there is no per-lane step / limit, no zero page, no checked twin of every issue and no pointer
+// rewind at the k-rotation's wrap.  What this buys is CODE SIZE in front of the first DMA: every dispatch starts with cold instruction and scalar
+// caches (the packet's acquire invalidates them), and the first workgroup of a launch on a CU walks the set-up at ~13 cycles per instruction instead
+// of ~4.5 (in-kernel stamps, scratch/gemm_lab.hip: entry -> ring primed 4100 cycles at the median against 1100 for a workgroup that finds the
+// code resident).
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false>
 __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_linear) {
     constexpr int NW = WM_ * WN_;
     constexpr int WTM = BM / WM_, WTN = BN / WN_, TM = WTM / 16, TN = WTN / 16;
@@ -589,13 +598,13 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     int tm, tn;
-    if (p.tiles_m_cm > 0) tile_from_linear(p.tiles_m_cm, p.tiles_m_magic, tile_linear, tn, tm);
+    if (!FAST && p.tiles_m_cm > 0) tile_from_linear(p.tiles_m_cm, p.tiles_m_magic, tile_linear, tn, tm);      // column-major tile order: lab (vqa_set_gemm_tile_order(2))
     else tile_from_linear(p.tiles_n, p.tiles_n_magic, tile_linear, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nk = (kend - kbeg + BKT - 1) / BKT;
-    const int nk_full = (kend - kbeg) / BKT;                 // tiles entirely inside K: no per-lane k check needed
+    const int kbeg = FAST ? 0 : blockIdx.z * p.k_per_split;
+    const int kend = FAST ? p.K : min(p.K, kbeg + p.k_per_split);
+    const int nk = FAST ? p.K / BKT : (kend - kbeg + BKT - 1) / BKT;
+    const int nk_full = FAST ? nk : (kend - kbeg) / BKT;     // tiles entirely inside K: no per-lane k check needed
 #ifdef VQA_GEMM_TRACE
     unsigned long long tr[32];
     for (int i = 0; i < 32; ++i) tr[i] = 0;
@@ -605,21 +614,58 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     // The ring is primed FIRST: the first tiles' flight from (cold) L2 / HBM -- ~2300 cycles on the in-kernel timeline -- runs
     // under the rest of the once-executed set-up code instead of after it.
     DmaLane da[PA], db[PB];
-    dma_init<BM, A_KC, BKT, NW>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
-    dma_init<BN, B_KC, BKT, NW>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+    unsigned long long fa_ptr[PA], fb_ptr[PB];               // FAST: this lane's 16 B of k tile 0
     // k ROTATION: the workgroups of XCD x (workgroups are dealt round-robin over the XCDs: x = blockIdx.x % 8) walk the k tiles starting x/8 of
     // the way through K and wrap around.  Every XCD reads the whole weight operand; started together at k = 0 all eight miss on the same lines
     // at the same time -- in the step the weights always come from HBM (profiles/r02/gemm_cold_weights.log: +2 - 4 us per launch) -- rotated, a
     // line is fetched from HBM for one XCD and found in the memory-side cache by the other seven.  fp32 accumulation order changes, nothing else.
     const int rot = (p.k_rotate && nk >= 8) ? (int)(((unsigned)((blockIdx.x + (p.k_rotate >> 8)) & 7) * (unsigned)nk) >> 3) : 0;
-    if (rot) {
+    int kk_next = rot;                                       // FAST: k tile the next issue fetches
+    if constexpr (FAST) {
+        constexpr int CPK = BKT / 8;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) da[i].ptr += (unsigned long long)rot * da[i].step;
+        for (int i = 0; i < PA; ++i) {
+            const int pos = (wave * PA + i) * 64 + lane;
+            if (A_KC) { const int r = pos / CPK, c = (pos % CPK) ^ kcT_key<BKT>(r); fa_ptr[i] = reinterpret_cast<unsigned long long>(p.a + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8); }
+            else { const int krow = pos / (BM / 8), c = (pos % (BM / 8)) ^ rc_key<BM>(krow); fa_ptr[i] = reinterpret_cast<unsigned long long>(p.a + (size_t)krow * p.lda + m0 + c * 8); }
+        }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) db[i].ptr += (unsigned long long)rot * db[i].step;
+        for (int i = 0; i < PB; ++i) {
+            const int pos = (wave * PB + i) * 64 + lane;
+            if (B_KC) { const int r = pos / CPK, c = (pos % CPK) ^ kcT_key<BKT>(r); fb_ptr[i] = reinterpret_cast<unsigned long long>(p.b + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8); }
+            else { const int krow = pos / (BN / 8), c = (pos % (BN / 8)) ^ rc_key<BN>(krow); fb_ptr[i] = reinterpret_cast<unsigned long long>(p.b + (size_t)krow * p.ldb + n0 + c * 8); }
+        }
+    } else {
+        dma_init<BM, A_KC, BKT, NW>(da, p.a, p.lda, m0, p.M, kbeg, kend, wave, lane);
+        dma_init<BN, B_KC, BKT, NW>(db, p.b, p.ldb, n0, p.N, kbeg, kend, wave, lane);
+        if (rot) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) da[i].ptr += (unsigned long long)rot * da[i].step;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) db[i].ptr += (unsigned long long)rot * db[i].step;
+        }
     }
+    const unsigned long long fa_step = A_KC ? (unsigned long long)(BKT * 2) : (unsigned long long)BKT * 2 * (unsigned)p.lda;
+    const unsigned long long fb_step = B_KC ? (unsigned long long)(BKT * 2) : (unsigned long long)BKT * 2 * (unsigned)p.ldb;
+    VQA_T(31);
     auto issue = [&](int t, int stage) {
         char* st = smem + stage * STAGE_BYTES;
+        if constexpr (FAST) {
+            const unsigned long long oa = (unsigned long long)(unsigned)kk_next * fa_step, ob = (unsigned long long)(unsigned)kk_next * fb_step;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                unsigned long long addr = fa_ptr[i] + oa;
+                asm volatile("" : "+v"(addr));
+                __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(st + (wave * PA + i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                unsigned long long addr = fb_ptr[i] + ob;
+                asm volatile("" : "+v"(addr));
+                __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(st + A_BYTES + (wave * PB + i) * 1024), 16, 0, 0);
+            }
+            kk_next = kk_next + 1 == nk ? 0 : kk_next + 1;
+        } else {
         int kk = t + rot;
         if (kk >= nk) kk -= nk;
         if (rot && kk == 0) {                                // wrap: this issue is k tile 0
@@ -630,6 +676,7 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
         }
         if (kk < nk_full) { dma_issue<PA, false>(da, st, 0, wave); dma_issue<PB, false>(db, st + A_BYTES, 0, wave); }
         else { dma_issue<PA, true>(da, st, kbeg + kk * BKT, wave); dma_issue<PB, true>(db, st + A_BYTES, kbeg + kk * BKT, wave); }
+        }
     };
 #pragma unroll
     for (int t = 0; t < STAGES1 - 1; ++t)
@@ -766,10 +813,10 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     constexpr int EG = epi_group<TM, TN>(STAGES1 * STAGE_BYTES, NW);
     constexpr int EGD = OPER_OK ? epi_group<TM, TN>(STAGES1 * STAGE_BYTES - NW * OPER, NW) : 1;
     if (OPER_OK && p.epi_dma)
-        gemm_epilogue<TM, TN, EGD, true>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EGD * EpiScratch<TN>::BYTES,
-                                         smem + NW * EGD * EpiScratch<TN>::BYTES + wave * OPER);
+        gemm_epilogue<TM, TN, EGD, true, FAST>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EGD * EpiScratch<TN>::BYTES,
+                                               smem + NW * EGD * EpiScratch<TN>::BYTES + wave * OPER);
     else
-        gemm_epilogue<TM, TN, EG>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
+        gemm_epilogue<TM, TN, EG, false, FAST>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
 #ifdef VQA_GEMM_TRACE
     VQA_T(27);
     wait_vmcnt<0>();
@@ -788,7 +835,7 @@ constexpr int ring_waves_per_simd(int lds_bytes, int nw) {
     int wg = 160 * 1024 / lds_bytes, w = wg * nw / 4;
     return w < 1 ? 1 : w > 4 ? 4 : w;
 }
-template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false>
 __global__ __launch_bounds__(WM_ * WN_ * 64) __attribute__((amdgpu_waves_per_eu(ring_waves_per_simd(STAGES1 * (BM + BN) * BKT * 2, WM_ * WN_))))
 void gemm_v1_kernel(const GemmArgs p) {
     const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
@@ -803,7 +850,14 @@ void gemm_v1_kernel(const GemmArgs p) {
     // ~40 argument words, its flag tests, the dropout / GELU constants, 60 SGPR spills into VGPR lanes) was hoisted by LICM into the loop
     // pre-header, i.e. IN FRONT of the first global_load_lds the body so carefully issues first: ~290 instructions and six kernarg round trips
     // before the ring was primed (ISA of round 3).
-    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, xcd_remap(blockIdx.x, ntiles));
+    // Every argument word the set-up reads, fetched as ONE batch of scalar loads: left alone, the compiler loads each word in the basic block that
+    // first needs it -- three DEPENDENT kernarg round trips before the first DMA (~1000 cycles each for the first workgroup of a launch on a CU:
+    // a launch's argument block is fresh memory, not in any cache).
+#ifndef VQA_ARGS_LAZY
+    asm volatile("" ::"s"(p.a), "s"(p.b), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb), "s"(p.k_per_split), "s"(p.tiles_n), "s"(p.tiles_n_magic),
+                 "s"(p.tiles_m_cm), "s"(p.tiles_m_magic), "s"(p.k_rotate), "s"(p.bias), "s"(p.sumsq));     // + one word of each remaining 64-B line
+#endif
+    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC, FAST>(p, xcd_remap(blockIdx.x, ntiles));
 #endif
 }
 
@@ -816,12 +870,16 @@ struct GroupArgs { int n; int k_rotate; float* sumsq; int tile_end[MAX_GROUP]; G
 
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
-    // PERSISTENT when the host launched fewer workgroups than tiles (vqa_set_gemm_group_persistent): workgroup b walks tiles
-    // b, b + G, b + 2G ...: the ~2 us of ramp every workgroup pays (kernel arguments, cold instruction cache) is paid once per
-    // workgroup instead of once per tile -- it matters for the experts' weight gradients, whose reduction is only 32 - 128 tokens long
+    // one tile per workgroup (the persistent form `for (tt = blockIdx.x; tt < total; tt += gridDim.x)` of rounds 1-2 is an A/B build only: see
+    // gemm_v1_kernel for what the loop cost every launch)
     const int total = g.tile_end[g.n - 1];
     int i = 0;
+#ifdef VQA_GEMM_PERSIST
     for (int tt = blockIdx.x; tt < total; tt += gridDim.x) {
+#else
+    {
+        const int tt = blockIdx.x;
+#endif
         const int t = xcd_remap(tt, total);
         if (t < (i ? g.tile_end[i - 1] : 0)) i = 0;
         while (i + 1 < g.n && t >= g.tile_end[i]) ++i;
@@ -834,7 +892,9 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const G
         p.k_rotate = g.k_rotate;
         p.sumsq = g.sumsq;
         gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
+#ifdef VQA_GEMM_PERSIST
         __syncthreads();                                     // the ring (epilogue scratch) is free again
+#endif
     }
 }
 
@@ -1068,6 +1128,7 @@ int g_tile_order = 0;      // 0 / 1: row-major tile ids (default: an XCD owns ro
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
+bool g_v1_fast = true;     // FAST instantiations of the ring kernel where the shape allows (vqa_set_gemm_v1_fast(0): A/B and tests of the general form)
 int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
 
 
@@ -1076,9 +1137,18 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
     constexpr int LDS = ST * (BM + BN) * BKT * 2;
     static bool attr_set = false;
     auto kern = gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC>;
+    // FAST instantiation (see gemm_v1_body) for the tiles the step's Linear layers run on
+    constexpr bool HAS_FAST = BM * BN <= 128 * 64;
+    if constexpr (HAS_FAST) {
+        if (g_v1_fast && splits == 1 && p.tiles_m_cm == 0 && p.K % BKT == 0 && (AK || p.M % BM == 0) && (BKC || p.N % BN == 0)) kern = gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC, true>;
+    }
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
+        if constexpr (HAS_FAST) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
@@ -1231,7 +1301,10 @@ extern "C" int vqa_gemm_profile_collect2(int ntags, double* flop, double* ms, in
 extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches) { return vqa_gemm_profile_collect2(ntags, flop, ms, launches, nullptr); }
 extern "C" void vqa_set_gemm_ws(int mode) { if (mode >= 0x100) { g_ws_mode = 1; g_ws_mask = (unsigned)(mode >> 8); } else { g_ws_mode = mode; g_ws_mask = 0xffffffffu; } }
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
+extern "C" void vqa_set_gemm_v1_fast(int on) { g_v1_fast = on != 0; }
+#ifdef VQA_GEMM_PERSIST
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
+#endif
 extern "C" void vqa_set_gemm_force(int cfg, int stages) { g_force_cfg = cfg; g_force_stages = stages; }
 extern "C" void vqa_set_gemm_tile_order(int order) { g_tile_order = order; }
 extern "C" void vqa_set_gemm_k_rotate(int on) { g_k_rotate = (on & 0xff) != 0; g_k_rotate_grouped = (on & 0xff) >= 2; g_k_rotate_phase = (on >> 8) & 7; }
@@ -1311,7 +1384,7 @@ extern "C" int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream_) {
     const int bn = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 128 : cfg == 3 ? 32 : cfg == 4 ? 64 : cfg == 7 ? 32 : cfg == 8 ? 64 : 128;
     const long tiles = (long)ceil_div(d->M, bm) * ceil_div(d->N, bn);
     p.tiles_n = ceil_div(d->N, bn); p.tiles_n_magic = div_magic(p.tiles_n);
-    p.tiles_m_cm = 0; p.tiles_m_magic = 0;
+    p.tiles_m_cm = 0; p.tiles_m_magic = div_magic(1);
     // only the encoder / fusion GEMMs over all tokens: their weights are what eight XCDs miss on together; the one-token-per-sample launches of the
     // experts and the head (M <= 128) have one or two tile rows, and their parity margins against the reference are the tightest of the path
     p.k_rotate = (g_k_rotate && d->M >= 256) ? (1 | (g_k_rotate_phase << 8)) : 0;
@@ -1386,14 +1459,18 @@ static int launch_grouped(const GroupArgs& g, hipStream_t st) {
         bytes += 2.0 * ((double)g.it[i].M + g.it[i].N) * g.it[i].K + 4.0 * (double)g.it[i].M * g.it[i].N;
     }
     int grid = g.tile_end[g.n - 1];
-    if (g_group_persistent > 0 && grid > g_group_persistent) grid = g_group_persistent / 8 * 8;      // a multiple of 8: the XCD remap stays a bijection
+#ifdef VQA_GEMM_PERSIST
+    if (g_group_persistent > 0 && grid > g_group_persistent) grid = g_group_persistent / 8 * 8;
+#endif
     vqa_launch(kern, dim3(grid), dim3(WM_ * WN_ * 64), LDS, st, g, flop, bytes);
     return (int)hipGetLastError();
 }
 
 int g_group_tile = 0;      // 0: heuristic; 1: 64x64; 2: 128x64; 3: 128x128 (diagnostics: vqa_set_gemm_group_tile)
 extern "C" void vqa_set_gemm_group_tile(int t) { g_group_tile = t; }
+#ifdef VQA_GEMM_PERSIST
 extern "C" void vqa_set_gemm_group_persistent(int n) { g_group_persistent = n; }
+#endif
 
 int g_dw256 = 1;            // 1 (default): weight-gradient items with 256-aligned outputs and 64-aligned token counts run on 256 x 256 tiles (gemm_dw256.h)
 extern "C" void vqa_set_gemm_dw256(int on) { g_dw256 = on; }

@@ -60,6 +60,7 @@ SIGNATURES = {
     'vqa_gemm_profile_collect2': (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     'vqa_set_gemm_ws': (None, [i32]),
     'vqa_set_gemm_use_tr': (None, [i32]),
+    'vqa_set_gemm_v1_fast': (None, [i32]),
     'vqa_set_gemm_pipeline': (None, [i32]),
     'vqa_cast_f32_bf16': (i32, [vp, vp, sz, vp]),
     'vqa_cast_multi': (i32, [vp, i32, u64, vp]),
@@ -112,8 +113,6 @@ SIGNATURES = {
     'vqa_gemm_bf16_grouped2': (i32, [vp, i32, i32, i32, vp, vp]),
     'vqa_set_gemm_dw256': (None, [i32]),
     'vqa_set_gemm_group_tile': (None, [i32]),
-    'vqa_set_gemm_group_persistent': (None, [i32]),
-    'vqa_set_gemm_grid_cap': (None, [i32]),
     'vqa_set_gemm_force': (None, [i32, i32]),
     'vqa_set_gemm_tile_order': (None, [i32]),
     'vqa_set_gemm_k_rotate': (None, [i32]),
@@ -183,6 +182,8 @@ def load(path: str = None):
         fn.restype, fn.argtypes = res, args
     if os.environ.get('VQA_DW256') is not None:               # A/B experiments only: 0 = weight gradients on the 128 x 128 ring kernel (round 2)
         lib.vqa_set_gemm_dw256(int(os.environ['VQA_DW256']))
+    if os.environ.get('VQA_GEMM_FAST') is not None:           # A/B experiments only: 0 = general-form ring kernels everywhere
+        lib.vqa_set_gemm_v1_fast(int(os.environ['VQA_GEMM_FAST']))
     if os.environ.get('VQA_GEMM_K_ROTATE') is not None:       # A/B experiments only (like VQA_HIP_LIB): per-XCD k rotation of the ring GEMMs off / on
         lib.vqa_set_gemm_k_rotate(int(os.environ['VQA_GEMM_K_ROTATE']))
     if path is None:
