@@ -183,7 +183,7 @@ def run_workload(workload, args, device, world, rank, dist, want_roofline):
         ok = 1
         try:
             graphed = GraphedTrainStep(model, opt, batch, warmup=3, reducer=reducer, segmented=True if getattr(args, 'force_segmented', False) else None,
-                                       moe_branches=1 if args.moe_branches is None else args.moe_branches, dp_split=args.dp_split,
+                                       moe_branches=1 if args.moe_branches is None else args.moe_branches, dp_split=args.dp_split, dp_segments=args.dp_segments,
                                        exchange_on_side_stream=not args.exchange_inline, wire_optimizer=not args.no_wire_optimizer,
                                        capture_error_mode='thread_local' if dist_on else 'global')
         except Exception as e:                       # noqa: BLE001 -- any capture failure means: run eagerly
@@ -369,6 +369,7 @@ def main():
     ap.add_argument('--moe-branches', type=int, default=None, help='diagnostics: MoE experts on side streams in the captured step (0 off, 1 specialised experts, 2 every expert)')
     ap.add_argument('--torch-optimizer', action='store_true', help='clip_grad_norm_ + torch fused AdamW instead of the HIP FusedAdamW')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from the host instead of replaying the captured HIP graph of the step')
+    ap.add_argument('--dp-segments', default='tapered', choices=['tapered', 'even'], help="depth split of the encoders' backward: 'tapered' = a one-layer last segment (its exchange is the exposed one), 'even' = equal segments (round 2)")
     ap.add_argument('--dp-split', default='depth', choices=['depth', 'towers'],
                     help="how the data-parallel captured step cuts the encoders' backward: 'depth' = up to four depth segments, text and vision layers of a segment as "
                          "parallel branches of one graph (default); 'towers' = text backward then vision backward, each in two graphs")

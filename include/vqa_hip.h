@@ -96,7 +96,7 @@ void vqa_set_gemm_k_rotate(int on);             /* low byte 1: workgroups of XCD
                                                  * bits 8..10: a phase added to x (another assignment of starting points = another fp32 summation order: tests) */
 void vqa_set_gemm_group_tile(int t);      /* diagnostics: 0 heuristic, 1: 64x64, 2: 128x64, 3: 128x128 */
 void vqa_set_gemm_use_tr(int on);          /* diagnostics: 0 = scalar LDS gather instead of ds_read_b64_tr_b16 */
-void vqa_set_gemm_v1_fast(int on);         /* 1 (default): ring GEMMs on whole tiles (K % 64 == 0, no split-K) run the compact-prologue instantiation; 0: the general form only (tests, A/B) */
+void vqa_set_gemm_v1_fast(int mode);       /* 1 (default): ring GEMMs on whole tiles (K % 64 == 0, no split-K) run the compact-prologue instantiation, with a compile-time epilogue where the launch's option set has one; 5: compact prologue, generic epilogue; 0: the general form only (tests, A/B) */
 void vqa_set_gemm_pipeline(int v1);        /* 0 = register-staged double buffer; 1 = LDS-DMA pipeline; 2/3/4 = LDS-DMA with that many stages */
 
 /* ---- elementwise / layout --------------------------------------------------------------------------------- */

@@ -38,7 +38,7 @@ nwg = len(t)
 t0 = t[:, 0].min()
 CLK = 1.0   # ticks; report in ticks and assume 100 MHz? print both
 span = t[:, 28].max() - t0
-steps = [(i, t[:, 2 + i]) for i in range(24) if (t[:, 2 + i] != 0).all()]
+steps = [(i, t[:, 2 + i]) for i in range(24 if Kd > 1152 else 18) if (t[:, 2 + i] != 0).all()]
 nst = len(steps)
 print(f'workgroups {nwg}, traced k-steps {nst}, kernel span {span} ticks')
 def stat(x): return f'min {x.min():7d} p50 {int(np.median(x)):7d} p90 {int(np.percentile(x, 90)):7d} max {x.max():7d}'
@@ -53,6 +53,9 @@ if nst > 1:
 last = steps[-1][1]
 print('last step->loopend', stat(t[:, 26] - last))
 print('epilogue issue    ', stat(t[:, 27] - t[:, 26]))
+if Kd <= 1152:
+    for i, nm in enumerate(['entry->bias etc', 'acc->scratch    ', 'rows of group 0 ', 'remaining groups']):
+        print('   epi', nm, stat(t[:, 20 + i] - (t[:, 26] if i == 0 else t[:, 19 + i])))
 print('store drain       ', stat(t[:, 28] - t[:, 27]))
 print('wg total          ', stat(t[:, 28] - t[:, 0]))
 print('end offset        ', stat(t[:, 28] - t0))

@@ -1129,3 +1129,50 @@ def test_compact_prologue_ring_kernels_equal_the_general_form_bit_for_bit():
         L.vqa_set_gemm_v1_fast(1)
         L.vqa_set_gemm_k_rotate(0)
         K._k_rotate_state = None
+
+
+def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
+    """The nine compile-time epilogue forms of the ring GEMM (csrc/gemm.hip: gemm_epilogue_s -- the option sets the encoders' Linear layers launch,
+    scratch/gemm_census.py) against the generic run-time-flag epilogue on the same FAST loop (vqa_set_gemm_v1_fast(5)) and on the general kernel
+    (0): every output stream identical to the bit (the fused bias-gradient column sums are fp32 atomics: to rounding), k rotation off and on,
+    whole and ragged row counts (1600 rows on 128-row tiles), dropout drawing the same mask."""
+    L = hl.load()
+    g = torch.Generator().manual_seed(11)
+
+    def real(shape, s=1.0):
+        return (torch.randn(shape, generator=g) * s).to(DEV)
+    kinds = [('NT', dict(bias=1, res=1, f32=1, drop=1)), ('NT', dict(bias=1, res=1, f32=1)), ('NN', dict(res=1, f32=1)), ('NN', dict(f32=1)), ('NN', dict(b16=1)),
+             ('NT', dict(bias=1, act=K.ACT_GELU, pre=1, b16=1)), ('NT', dict(bias=1, act=K.ACT_QUICK_GELU, pre=1, b16=1)),
+             ('NN', dict(actb=K.ACT_GELU, b16=1, colsum=1)), ('NN', dict(actb=K.ACT_QUICK_GELU, b16=1, colsum=1))]
+    try:
+        for (M, N, Kd) in [(2048, 768, 768), (1600, 768, 3072), (2048, 3072, 768), (1600, 3072, 768), (256, 64, 64), (512, 1536, 128)]:
+            a = real((M, Kd)).to(BF)
+            w_nt = real((N, Kd), 1.0 / math.sqrt(Kd)).to(BF)
+            w_nn = w_nt.t().contiguous()
+            bias, res, z = real((N,)), real((M, N)), real((M, N)).to(BF)
+            for lay, o in kinds:
+                for rot in (0, 1):
+                    L.vqa_set_gemm_k_rotate(rot)
+                    outs = []
+                    for mode in (1, 5, 0):
+                        L.vqa_set_gemm_v1_fast(mode)
+                        of = torch.zeros((M, N), device=DEV) if o.get('f32') else None
+                        ob = torch.zeros((M, N), device=DEV, dtype=BF) if o.get('b16') else None
+                        pre = torch.zeros((M, N), device=DEV, dtype=BF) if o.get('pre') else None
+                        cs = torch.zeros((N,), device=DEV) if o.get('colsum') else None
+                        K.gemm(a, w_nt if lay == 'NT' else w_nn, M, N, Kd, Kd, Kd if lay == 'NT' else N, True, lay == 'NT', out_f32=of, out_bf16=ob, pre_bf16=pre,
+                               bias=bias if o.get('bias') else None, residual=res if o.get('res') else None, act_grad_of=z if o.get('actb') else None,
+                               act=o.get('act', K.ACT_NONE), act_bwd=o.get('actb', K.ACT_NONE), drop=K.Drop(0.1, 99, 3) if o.get('drop') else K.NO_DROP, colsum=cs)
+                        outs.append((of, ob, pre, cs))
+                    for other in outs[1:]:
+                        for x, y in zip(outs[0][:3], other[:3]):
+                            assert (x is None and y is None) or torch.equal(x, y), (M, N, Kd, lay, o, rot)
+                        if outs[0][3] is not None:
+                            assert torch.allclose(outs[0][3], other[3], rtol=1e-4, atol=2e-3), (M, N, Kd, lay, o, rot)
+                    if o.get('drop'):
+                        kept = (outs[0][0] != res).float().mean().item()          # dropped elements leave the residual unchanged
+                        assert abs(kept - 0.9) < 0.01, kept
+    finally:
+        L.vqa_set_gemm_v1_fast(1)
+        L.vqa_set_gemm_k_rotate(0)
+        K._k_rotate_state = None

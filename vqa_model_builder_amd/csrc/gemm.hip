@@ -237,7 +237,16 @@ template <int TM, int TN> constexpr int epi_group(int avail, int nw) {
 // overwrites the register the other path's global load may still be filling.)
 template <int TM, int TN> constexpr int epi_oper_bytes() { return (TM * 16 * TN * 16 * 4 + 1023) / 1024 * 1024; }     // sized for fp32
 template <int TM, int TN, int G, bool ODMA = false, bool NOSPLIT = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch, char* oper = nullptr) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch, char* oper = nullptr
+#ifdef VQA_GEMM_TRACE
+                                              , unsigned long long* etr = nullptr
+#endif
+                                              ) {
+#ifdef VQA_GEMM_TRACE
+#define VQA_ET(i) do { if (etr) etr[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VQA_ET(i) do { } while (0)
+#endif
     const bool splitk = !NOSPLIT && gridDim.z > 1;
     // dropout key: resolved here, at its only use (an INDIRECT seed costs one scalar load whose latency hides behind the stores);
     // resolving it at kernel entry by patching a copy of the argument struct put the struct in scratch memory and opened every
@@ -273,6 +282,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     float ssq = 0.f;
+    VQA_ET(0);
     const int okind = ODMA ? p.epi_dma : 0;
     const int oper_rb = TN * 16 * (okind == 1 ? 2 : 4);                 // bytes per row of the wave tile in the staged operand
     if (ODMA) {
@@ -306,6 +316,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         if (ODMA && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the staged operand landed (under the turn's LDS writes)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (g == 0) VQA_ET(1);
         // ROLLED (the body carries every fused option; unrolled TM x 16/RPI times it was ~100 KB of once-executed code that ran at
         // instruction-fetch speed -- and even a 4x unrolled chunk measured 6 % slower over the step than this form: at one cold
         // launch per kernel, code size is time).
@@ -355,7 +366,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
         }
         __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
+        if (g == 0) VQA_ET(2);
     }
+    VQA_ET(3);
     if (p.sumsq) {
         ssq = wave_sum(ssq);
         if (lane == 0) atomicAdd(p.sumsq, ssq);
@@ -369,6 +382,136 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                 cs[r] = o == 4 ? cs[r] + dpp_f32<0x124>(cs[r]) : o == 8 ? cs[r] + dpp_f32<0x128>(cs[r]) : o == 16 ? xor16_sum(cs[r]) : xor32_sum(cs[r]);
         }
         if (lane < LPR && nok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, cs[r]);
+        }
+    }
+}
+
+// ---- SPECIALISED epilogues -------------------------------------------------------------------------------------------------------------
+// The generic epilogue above carries every fused option behind run-time flags, so its row loop must stay rolled (unrolled it is ~100 KB of
+// once-executed code) -- and a rolled body is one long dependent chain per iteration: LDS read -> wait -> a dozen skipped option branches ->
+// convert -> store, ~600 - 700 cycles per 8 rows with 1.5 waves per SIMD left to hide anything (in-kernel stamps, scratch/gemm_lab.hip: the
+// epilogue of a 64 x 64 tile is 4 such iterations + 1700 cycles of cold set-up = 5000 of the workgroup's 19 000 cycles at K = 768).  The step's
+// Linear layers use NINE option sets on two tiles (scratch/gemm_census.py); for those the option set is a template argument (EPI): the flags
+// fold at compile time, the body shrinks to the options in use, and all rows of a strip group go through as ONE batch -- every LDS read issued,
+// one wait, the arithmetic of the rows interleaved, the stores back to back.  Same operations in the same order per element as the generic
+// form (fp contraction off here: `v * keep + residual` sits in one basic block in this form and must not become an FMA the generic form
+// cannot form), so the two agree to the bit (tests/test_kernels_gpu.py::test_specialised_epilogues_equal_the_generic_form_bit_for_bit).
+enum : unsigned { E_S = 1u, E_BIAS = 2u, E_PRE = 4u, E_DROP = 8u, E_RES = 16u, E_F32 = 32u, E_B16 = 64u, E_COLSUM = 128u, E_ACT_SHIFT = 8, E_ACTB_SHIFT = 11 };
+constexpr unsigned epi_make(bool bias, int act, bool pre, int actb, bool drop, bool res, bool f32, bool b16, bool colsum) {
+    return E_S | (bias ? E_BIAS : 0u) | (pre ? E_PRE : 0u) | (drop ? E_DROP : 0u) | (res ? E_RES : 0u) | (f32 ? E_F32 : 0u) | (b16 ? E_B16 : 0u) | (colsum ? E_COLSUM : 0u) |
+           ((unsigned)act << E_ACT_SHIFT) | ((unsigned)actb << E_ACTB_SHIFT);
+}
+// option set of a launch, or 0 when it has something no specialisation carries (alpha, fused sum of squares)
+static inline unsigned epi_code(const GemmArgs& p) {
+    if (p.alpha != 1.0f || p.sumsq) return 0u;
+    return epi_make(p.bias != nullptr, p.act, p.pre_bf16 != nullptr, p.act_grad_of ? p.act_bwd_kind : 0, p.drop_p > 0.f, p.residual != nullptr, p.c_f32 != nullptr,
+                    p.c_bf16 != nullptr, p.colsum != nullptr);
+}
+
+template <int TM, int TN, int G, bool ODMA, unsigned EPI>
+__device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch, char* oper) {
+#pragma clang fp contract(off)
+    constexpr bool BIAS = (EPI & E_BIAS) != 0, PRE = (EPI & E_PRE) != 0, DROP = (EPI & E_DROP) != 0, RES = (EPI & E_RES) != 0, F32 = (EPI & E_F32) != 0,
+                   B16 = (EPI & E_B16) != 0, CS = (EPI & E_COLSUM) != 0;
+    constexpr int ACT = (EPI >> E_ACT_SHIFT) & 7, ACTB = (EPI >> E_ACTB_SHIFT) & 7;
+    static_assert(!ODMA || (RES != (ACTB != 0)), "the staged operand is the residual or the saved pre-activation, exactly one");
+    static_assert(ODMA || (!RES && ACTB == 0), "a global epilogue operand is always staged in this form");
+    constexpr int PITCH = EpiScratch<TN>::PITCH, LPR = 4 * TN, RPI = 64 / LPR, NQ = G * 16 / RPI;
+    constexpr int OESZ = ACTB ? 2 : 4, OPER_RB = TN * 16 * OESZ;              // staged operand: element size, bytes per row of the wave tile
+    const int wr_off = (lane & 15) * PITCH + (lane >> 4) * 16;
+    const int rd_row = lane / LPR, col = 4 * (lane % LPR);
+    const int n = n_base + col;                                                // whole tiles in N (host), N % 4 == 0
+    if (ODMA) {
+        constexpr int OLPR = OPER_RB >> 4, ORPI = 64 / OLPR;                   // 16-B lanes per row, rows per 1-KiB DMA instruction
+        const char* gsrc = ACTB ? reinterpret_cast<const char*>(p.act_grad_of) : reinterpret_cast<const char*>(p.residual);
+        const size_t pitch = (size_t)(ACTB ? p.ld_ag : p.ld_res) * OESZ;
+#pragma unroll
+        for (int i = 0; i * ORPI < TM * 16; ++i) {
+            const int row = i * ORPI + lane / OLPR;
+            const int m = min(m_base + row, p.M - 1);                          // clamped rows are never used
+            unsigned long long addr = reinterpret_cast<unsigned long long>(gsrc + (size_t)m * pitch + (size_t)(n_base + (lane % OLPR) * (16 / OESZ)) * OESZ);
+            asm volatile("" : "+v"(addr));
+            __builtin_amdgcn_global_load_lds((gptr_t*)addr, (lptr_t*)(oper + i * 1024), 16, 0, 0);
+        }
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const uint64_t drop_seed = DROP ? resolve_seed(p.drop_seed) : 0ull;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    const unsigned sbase = (unsigned)(uintptr_t)scratch + rd_row * PITCH + col * 4;
+    const unsigned obase = ODMA ? (unsigned)(uintptr_t)oper + rd_row * OPER_RB + col * OESZ : 0u;
+#pragma unroll
+    for (int g = 0; g < TM / G; ++g) {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(scratch + i * EpiScratch<TN>::BYTES + wr_off + j * 64) = acc[g * G + i][j];
+        if (ODMA && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the staged operand landed (under the turn's LDS writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 v[NQ], rv[NQ];
+        h16x4 pv[NQ];
+        // every LDS read of the batch through inline asm, one wait behind them (plain loads would be waited for one by one, and behind a plain
+        // load of the staged operand the compiler also waits for the previous group's global stores: they share vmcnt with the DMA)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[q]) : "v"(sbase + q * RPI * PITCH));
+            if (ODMA) {
+                const unsigned oa = obase + (16 * g * G + q * RPI) * OPER_RB;
+                if (ACTB) asm volatile("ds_read_b64 %0, %1" : "=v"(pv[q]) : "v"(oa));
+                else asm volatile("ds_read_b128 %0, %1" : "=v"(rv[q]) : "v"(oa));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            asm volatile("" : "+v"(v[q]));
+            if (ODMA && ACTB) asm volatile("" : "+v"(pv[q]));
+            if (ODMA && !ACTB) asm volatile("" : "+v"(rv[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int m = m_base + 16 * g * G + q * RPI + rd_row;
+            if (m < p.M) {
+                f32x4 x = v[q] + bv;
+                if (ACTB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] *= act_bwd((float)pv[q][r], ACTB);
+                }
+                if (PRE) {
+                    h16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (h16_t)x[r];
+                    *reinterpret_cast<h16x4*>(p.pre_bf16 + (size_t)m * p.ld_pre + n) = o;
+                }
+                if (ACT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = act_fwd(x[r], ACT);
+                }
+                if (DROP) x *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
+                if (CS) cs += x;
+                if (RES) x += rv[q];
+                if (F32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = x;
+                if (B16) {
+                    h16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (h16_t)x[r];
+                    *reinterpret_cast<h16x4*>(p.c_bf16 + (size_t)m * p.ldc_bf16 + n) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
+    }
+    if (CS) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[r] = o == 4 ? cs[r] + dpp_f32<0x124>(cs[r]) : o == 8 ? cs[r] + dpp_f32<0x128>(cs[r]) : o == 16 ? xor16_sum(cs[r]) : xor32_sum(cs[r]);
+        }
+        if (lane < LPR) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, cs[r]);
         }
@@ -584,8 +727,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // caches (the packet's acquire invalidates them), and the first workgroup of a launch on a CU walks the set-up at ~13 cycles per instruction instead
 // of ~4.5 (in-kernel stamps, scratch/gemm_lab.hip: entry -> ring primed 4100 cycles at the median against 1100 for a workgroup that finds the
 // code resident).
-template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false>
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false, unsigned EPI = 0>
 __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_linear) {
+    static_assert(EPI == 0 || FAST, "specialised epilogues assume whole tiles");
     constexpr int NW = WM_ * WN_;
     constexpr int WTM = BM / WM_, WTN = BN / WN_, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -812,11 +956,24 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
     constexpr bool OPER_OK = NW * (EpiScratch<TN>::BYTES + OPER) <= STAGES1 * STAGE_BYTES;
     constexpr int EG = epi_group<TM, TN>(STAGES1 * STAGE_BYTES, NW);
     constexpr int EGD = OPER_OK ? epi_group<TM, TN>(STAGES1 * STAGE_BYTES - NW * OPER, NW) : 1;
+    if constexpr (EPI != 0) {
+        constexpr bool S_ODMA = ((EPI & E_RES) != 0) != (((EPI >> E_ACTB_SHIFT) & 7) != 0);
+        static_assert(!S_ODMA || OPER_OK, "the staged operand must fit the ring");
+        if constexpr (S_ODMA)
+            gemm_epilogue_s<TM, TN, EGD, true, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EGD * EpiScratch<TN>::BYTES,
+                                                    smem + NW * EGD * EpiScratch<TN>::BYTES + wave * OPER);
+        else
+            gemm_epilogue_s<TM, TN, EG, false, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES, nullptr);
+    } else
     if (OPER_OK && p.epi_dma)
         gemm_epilogue<TM, TN, EGD, true, FAST>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EGD * EpiScratch<TN>::BYTES,
                                                smem + NW * EGD * EpiScratch<TN>::BYTES + wave * OPER);
     else
-        gemm_epilogue<TM, TN, EG, false, FAST>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES);
+        gemm_epilogue<TM, TN, EG, false, FAST>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * EG * EpiScratch<TN>::BYTES
+#ifdef VQA_GEMM_TRACE
+                                               , nullptr, wave == 0 ? tr + 20 : nullptr
+#endif
+                                               );
 #ifdef VQA_GEMM_TRACE
     VQA_T(27);
     wait_vmcnt<0>();
@@ -835,7 +992,7 @@ constexpr int ring_waves_per_simd(int lds_bytes, int nw) {
     int wg = 160 * 1024 / lds_bytes, w = wg * nw / 4;
     return w < 1 ? 1 : w > 4 ? 4 : w;
 }
-template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false>
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false, unsigned EPI = 0>
 __global__ __launch_bounds__(WM_ * WN_ * 64) __attribute__((amdgpu_waves_per_eu(ring_waves_per_simd(STAGES1 * (BM + BN) * BKT * 2, WM_ * WN_))))
 void gemm_v1_kernel(const GemmArgs p) {
     const int ntiles = p.tiles_n * ((p.M + BM - 1) / BM);
@@ -857,7 +1014,7 @@ void gemm_v1_kernel(const GemmArgs p) {
     asm volatile("" ::"s"(p.a), "s"(p.b), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb), "s"(p.k_per_split), "s"(p.tiles_n), "s"(p.tiles_n_magic),
                  "s"(p.tiles_m_cm), "s"(p.tiles_m_magic), "s"(p.k_rotate), "s"(p.bias), "s"(p.sumsq));     // + one word of each remaining 64-B line
 #endif
-    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC, FAST>(p, xcd_remap(blockIdx.x, ntiles));
+    gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC, FAST, EPI>(p, xcd_remap(blockIdx.x, ntiles));
 #endif
 }
 
@@ -1128,6 +1285,7 @@ int g_tile_order = 0;      // 0 / 1: row-major tile ids (default: an XCD owns ro
 int g_grid_cap = 0;        // > 0: persistent LDS-DMA GEMMs on at most this many workgroups (vqa_set_gemm_grid_cap)
 bool g_use_v1 = false;     // diagnostics: tile_hint launches use the LDS-DMA kernel when set
 bool g_force_dma = false;
+bool g_v1_epi = true;      // specialised epilogues (gemm_epilogue_s) where a launch's option set has one (vqa_set_gemm_v1_fast(1 | 2): bit 1 = 0 switches them off)
 bool g_v1_fast = true;     // FAST instantiations of the ring kernel where the shape allows (vqa_set_gemm_v1_fast(0): A/B and tests of the general form)
 int g_v1_stages = 2;       // measured: occupancy (32-KiB workgroups) beats deeper DMA rings at K <= 3072
 
@@ -1140,7 +1298,35 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
     // FAST instantiation (see gemm_v1_body) for the tiles the step's Linear layers run on
     constexpr bool HAS_FAST = BM * BN <= 128 * 64;
     if constexpr (HAS_FAST) {
-        if (g_v1_fast && splits == 1 && p.tiles_m_cm == 0 && p.K % BKT == 0 && (AK || p.M % BM == 0) && (BKC || p.N % BN == 0)) kern = gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC, true>;
+        if (g_v1_fast && splits == 1 && p.tiles_m_cm == 0 && p.K % BKT == 0 && (AK || p.M % BM == 0) && (BKC || p.N % BN == 0)) {
+            kern = gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC, true>;
+            // the step's nine Linear-layer option sets on their two tiles (scratch/gemm_census.py; gemm_epilogue_s): a global epilogue operand must be
+            // the staged one (epi_dma: alignment checked by the caller)
+            const unsigned code = (g_v1_epi && p.N % BN == 0) ? epi_code(p) : 0u;
+            const bool staged_ok = (p.residual == nullptr && p.act_grad_of == nullptr) || p.epi_dma != 0;
+#define VQA_EPI(...) if (code == epi_make(__VA_ARGS__)) kern = gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC, true, epi_make(__VA_ARGS__)>
+            if (code && staged_ok) {
+                //                          bias   act             pre    act'            drop   res    f32    b16    colsum
+                if constexpr (BM == 64 && BN == 64 && ST == 3 && AK && BKC) {
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, true, true, true, false, false);          // out_proj / fc2 forward, text tower (hidden dropout)
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, false, true, true, false, false);         // out_proj / fc2 forward, vision tower
+                }
+                if constexpr (BM == 64 && BN == 64 && ST == 3 && AK && !BKC) {
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, true, true, false, false);        // input gradient + the residual stream's gradient
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, false, true, false, false);       // input gradient, fp32
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, false, false, true, false);       // input gradient, 16-bit
+                }
+                if constexpr (BM == 128 && BN == 64 && ST == 2 && AK && BKC) {
+                    VQA_EPI(true, ACT_GELU_ERF, true, ACT_NONE, false, false, false, true, false);     // fc1 forward, text tower
+                    VQA_EPI(true, ACT_QUICK_GELU, true, ACT_NONE, false, false, false, true, false);   // fc1 forward, vision tower
+                }
+                if constexpr (BM == 128 && BN == 64 && ST == 2 && AK && !BKC) {
+                    VQA_EPI(false, ACT_NONE, false, ACT_GELU_ERF, false, false, false, true, true);    // fc2 input gradient x GELU'(z), + fc1's bias gradient
+                    VQA_EPI(false, ACT_NONE, false, ACT_QUICK_GELU, false, false, false, true, true);
+                }
+            }
+#undef VQA_EPI
+        }
     }
     if (!attr_set && LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v1_kernel<BM, BN, WM_, WN_, BKT, ST, AK, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1301,7 +1487,7 @@ extern "C" int vqa_gemm_profile_collect2(int ntags, double* flop, double* ms, in
 extern "C" int vqa_gemm_profile_collect(int ntags, double* flop, double* ms, int* launches) { return vqa_gemm_profile_collect2(ntags, flop, ms, launches, nullptr); }
 extern "C" void vqa_set_gemm_ws(int mode) { if (mode >= 0x100) { g_ws_mode = 1; g_ws_mask = (unsigned)(mode >> 8); } else { g_ws_mode = mode; g_ws_mask = 0xffffffffu; } }
 extern "C" void vqa_set_gemm_use_tr(int on) { g_use_tr = on != 0; }
-extern "C" void vqa_set_gemm_v1_fast(int on) { g_v1_fast = on != 0; }
+extern "C" void vqa_set_gemm_v1_fast(int on) { g_v1_fast = (on & 1) != 0; g_v1_epi = on == 1 || (on & 2) != 0; }      // 0: general form; 1: default; 5: FAST without the specialised epilogues
 #ifdef VQA_GEMM_PERSIST
 extern "C" void vqa_set_gemm_grid_cap(int cap) { g_grid_cap = cap; }
 #endif

@@ -51,7 +51,7 @@ class GraphedTrainStep:
                  reducer=None, warmup: int = 3, parallel_towers: bool = True,
                  capture_error_mode: str = 'global', capture_stream=None, defer_wgrad: bool = True, segmented: Optional[bool] = None,
                  moe_branches: int = 1, split_encoders: bool = True, sparse_embeddings: bool = True, dp_split: str = 'depth',
-                 exchange_on_side_stream: bool = True, wire_optimizer: bool = True):
+                 exchange_on_side_stream: bool = True, wire_optimizer: bool = True, dp_segments: str = 'tapered'):
         """``batch``: keyword tensors of ``model.forward`` (shapes are fixed by the capture).
         Construct this BEFORE training the model eagerly on the default stream (or run such steps under
         ``torch.cuda.stream(side_stream)``): autograd binds each parameter's gradient-accumulation node to the stream of its
@@ -65,6 +65,7 @@ class GraphedTrainStep:
         ``dp_split`` (segmented step): 'depth' (default) cuts BOTH encoders' backward by depth into up to four graphs B1 .. B4, each
         holding the text and the vision layers of that depth as parallel branches (the two towers keep filling each other's gaps, as in
         the one-graph step); 'towers' is the first form of this round: text backward (T, T2) then vision backward (V, V2), one tower at a time.
+        ``dp_segments`` (depth split): 'tapered' (default) = a one-layer last segment, 'even' = equal segments.
         ``exchange_on_side_stream`` (segmented step): each segment's pack / all-reduce / unpack chain runs on a stream of its own.
         ``wire_optimizer`` (segmented step, bf16 buckets, FusedAdamW): the optimiser reads the summed bfloat16 gradients in the exchange's
         staging buffers; ``p.grad`` keeps the rank's local gradient.
@@ -100,8 +101,20 @@ class GraphedTrainStep:
                 and min(tb.config.num_hidden_layers, vb.config.num_hidden_layers) >= 2 and getattr(model, 'parallel_towers', False)):
             # depth-wise segments: segment j of n holds layers [cut[j], cut[j-1]) of each tower (descending), the last one the embeddings too
             n = min(4, tb.config.num_hidden_layers, vb.config.num_hidden_layers)
-            self._depth = {'n': n, 'blocks': {'T': tb, 'V': vb},
-                           'cuts': {k: [b.config.num_hidden_layers - (b.config.num_hidden_layers * j) // n for j in range(1, n)] for k, b in (('T', tb), ('V', vb))}}
+
+            def cuts_of(L):
+                # descending layer boundaries.  'tapered' (default): the LAST segment is one layer (+ the embeddings) -- its exchange is the one
+                # nothing can hide, so it is made the smallest (28 MB of bf16 per layer pair instead of 85 MB) -- and the other L - 1 layers are
+                # dealt evenly over the first n - 1 segments; 'even': L / n layers each (round 2)
+                if dp_segments == 'even' or n == 1:
+                    return [L - (L * j) // n for j in range(1, n)]
+                sizes = [(L - 1) // (n - 1) + (1 if j < (L - 1) % (n - 1) else 0) for j in range(n - 1)]
+                out, at = [], L
+                for sz in sizes:
+                    at -= sz
+                    out.append(at)
+                return out
+            self._depth = {'n': n, 'blocks': {'T': tb, 'V': vb}, 'cuts': {k: cuts_of(b.config.num_hidden_layers) for k, b in (('T', tb), ('V', vb))}}
             self._order = ('H',) + tuple(f'B{j + 1}' for j in range(n))
         elif self.segmented and split_encoders:
             order = ['H']
