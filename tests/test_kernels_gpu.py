@@ -1143,9 +1143,12 @@ def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
         return (torch.randn(shape, generator=g) * s).to(DEV)
     kinds = [('NT', dict(bias=1, res=1, f32=1, drop=1)), ('NT', dict(bias=1, res=1, f32=1)), ('NN', dict(res=1, f32=1)), ('NN', dict(f32=1)), ('NN', dict(b16=1)),
              ('NT', dict(bias=1, act=K.ACT_GELU, pre=1, b16=1)), ('NT', dict(bias=1, act=K.ACT_QUICK_GELU, pre=1, b16=1)),
-             ('NN', dict(actb=K.ACT_GELU, b16=1, colsum=1)), ('NN', dict(actb=K.ACT_QUICK_GELU, b16=1, colsum=1))]
+             ('NN', dict(actb=K.ACT_GELU, b16=1, colsum=1)), ('NN', dict(actb=K.ACT_QUICK_GELU, b16=1, colsum=1)),
+             # generative layers, the 64 000-way head's form, the experts' / answer head's 32 x 32-tile launches
+             ('NT', dict(bias=1, b16=1)), ('NT', dict(f32=1)), ('NT', dict(bias=1, act=K.ACT_GELU, pre=1, drop=1, b16=1)),
+             ('NN', dict(actb=K.ACT_GELU, drop=1, b16=1, colsum=1)), ('NT', dict(bias=1, f32=1))]
     try:
-        for (M, N, Kd) in [(2048, 768, 768), (1600, 768, 3072), (2048, 3072, 768), (1600, 3072, 768), (256, 64, 64), (512, 1536, 128)]:
+        for (M, N, Kd) in [(2048, 768, 768), (1600, 768, 3072), (2048, 3072, 768), (1600, 3072, 768), (256, 64, 64), (512, 1536, 128), (128, 2048, 768), (32, 768, 2048), (72, 96, 64)]:
             a = real((M, Kd)).to(BF)
             w_nt = real((N, Kd), 1.0 / math.sqrt(Kd)).to(BF)
             w_nn = w_nt.t().contiguous()
@@ -1169,7 +1172,7 @@ def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
                             assert (x is None and y is None) or torch.equal(x, y), (M, N, Kd, lay, o, rot)
                         if outs[0][3] is not None:
                             assert torch.allclose(outs[0][3], other[3], rtol=1e-4, atol=2e-3), (M, N, Kd, lay, o, rot)
-                    if o.get('drop'):
+                    if o.get('drop') and o.get('res') and M * N >= 1 << 20:
                         kept = (outs[0][0] != res).float().mean().item()          # dropped elements leave the residual unchanged
                         assert abs(kept - 0.9) < 0.01, kept
     finally:

@@ -398,23 +398,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 // one wait, the arithmetic of the rows interleaved, the stores back to back.  Same operations in the same order per element as the generic
 // form (fp contraction off here: `v * keep + residual` sits in one basic block in this form and must not become an FMA the generic form
 // cannot form), so the two agree to the bit (tests/test_kernels_gpu.py::test_specialised_epilogues_equal_the_generic_form_bit_for_bit).
-enum : unsigned { E_S = 1u, E_BIAS = 2u, E_PRE = 4u, E_DROP = 8u, E_RES = 16u, E_F32 = 32u, E_B16 = 64u, E_COLSUM = 128u, E_ACT_SHIFT = 8, E_ACTB_SHIFT = 11 };
-constexpr unsigned epi_make(bool bias, int act, bool pre, int actb, bool drop, bool res, bool f32, bool b16, bool colsum) {
+enum : unsigned { E_S = 1u, E_BIAS = 2u, E_PRE = 4u, E_DROP = 8u, E_RES = 16u, E_F32 = 32u, E_B16 = 64u, E_COLSUM = 128u, E_ACT_SHIFT = 8, E_ACTB_SHIFT = 11, E_SUMSQ = 1u << 14 };
+constexpr unsigned epi_make(bool bias, int act, bool pre, int actb, bool drop, bool res, bool f32, bool b16, bool colsum, bool sumsq = false) {
     return E_S | (bias ? E_BIAS : 0u) | (pre ? E_PRE : 0u) | (drop ? E_DROP : 0u) | (res ? E_RES : 0u) | (f32 ? E_F32 : 0u) | (b16 ? E_B16 : 0u) | (colsum ? E_COLSUM : 0u) |
-           ((unsigned)act << E_ACT_SHIFT) | ((unsigned)actb << E_ACTB_SHIFT);
+           ((unsigned)act << E_ACT_SHIFT) | ((unsigned)actb << E_ACTB_SHIFT) | (sumsq ? E_SUMSQ : 0u);
 }
-// option set of a launch, or 0 when it has something no specialisation carries (alpha, fused sum of squares)
+// option set of a launch, or 0 when it has something no specialisation carries (alpha)
 static inline unsigned epi_code(const GemmArgs& p) {
-    if (p.alpha != 1.0f || p.sumsq) return 0u;
+    if (p.alpha != 1.0f) return 0u;
     return epi_make(p.bias != nullptr, p.act, p.pre_bf16 != nullptr, p.act_grad_of ? p.act_bwd_kind : 0, p.drop_p > 0.f, p.residual != nullptr, p.c_f32 != nullptr,
-                    p.c_bf16 != nullptr, p.colsum != nullptr);
+                    p.c_bf16 != nullptr, p.colsum != nullptr, p.sumsq != nullptr);
 }
 
 template <int TM, int TN, int G, bool ODMA, unsigned EPI>
 __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[TM][TN], int m_base, int n_base, int lane, char* scratch, char* oper) {
 #pragma clang fp contract(off)
     constexpr bool BIAS = (EPI & E_BIAS) != 0, PRE = (EPI & E_PRE) != 0, DROP = (EPI & E_DROP) != 0, RES = (EPI & E_RES) != 0, F32 = (EPI & E_F32) != 0,
-                   B16 = (EPI & E_B16) != 0, CS = (EPI & E_COLSUM) != 0;
+                   B16 = (EPI & E_B16) != 0, CS = (EPI & E_COLSUM) != 0, SSQ = (EPI & E_SUMSQ) != 0;
     constexpr int ACT = (EPI >> E_ACT_SHIFT) & 7, ACTB = (EPI >> E_ACTB_SHIFT) & 7;
     static_assert(!ODMA || (RES != (ACTB != 0)), "the staged operand is the residual or the saved pre-activation, exactly one");
     static_assert(ODMA || (!RES && ACTB == 0), "a global epilogue operand is always staged in this form");
@@ -422,7 +422,8 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
     constexpr int OESZ = ACTB ? 2 : 4, OPER_RB = TN * 16 * OESZ;              // staged operand: element size, bytes per row of the wave tile
     const int wr_off = (lane & 15) * PITCH + (lane >> 4) * 16;
     const int rd_row = lane / LPR, col = 4 * (lane % LPR);
-    const int n = n_base + col;                                                // whole tiles in N (host), N % 4 == 0
+    const int n = n_base + col;
+    const bool nok = n < p.N;                                                  // N % 4 == 0 (host); with a staged operand whole tiles in N as well
     if (ODMA) {
         constexpr int OLPR = OPER_RB >> 4, ORPI = 64 / OLPR;                   // 16-B lanes per row, rows per 1-KiB DMA instruction
         const char* gsrc = ACTB ? reinterpret_cast<const char*>(p.act_grad_of) : reinterpret_cast<const char*>(p.residual);
@@ -437,9 +438,10 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
         }
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (BIAS) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (BIAS && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     const uint64_t drop_seed = DROP ? resolve_seed(p.drop_seed) : 0ull;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    float ssq = 0.f;
     const unsigned sbase = (unsigned)(uintptr_t)scratch + rd_row * PITCH + col * 4;
     const unsigned obase = ODMA ? (unsigned)(uintptr_t)oper + rd_row * OPER_RB + col * OESZ : 0u;
 #pragma unroll
@@ -474,7 +476,7 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int m = m_base + 16 * g * G + q * RPI + rd_row;
-            if (m < p.M) {
+            if (m < p.M && nok) {
                 f32x4 x = v[q] + bv;
                 if (ACTB) {
 #pragma unroll
@@ -493,6 +495,7 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
                 if (DROP) x *= dropout_scale4(drop_seed, p.drop_stream, (uint64_t)m * p.N + n, p.drop_p, p.drop_inv_keep);
                 if (CS) cs += x;
                 if (RES) x += rv[q];
+                if (SSQ) ssq += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
                 if (F32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = x;
                 if (B16) {
                     h16x4 o;
@@ -504,6 +507,10 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
         }
         __builtin_amdgcn_wave_barrier();                 // LDS executes a wave's accesses in order: the next group's writes follow these reads
     }
+    if (SSQ) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) atomicAdd(p.sumsq, ssq);
+    }
     if (CS) {
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) {
@@ -511,7 +518,7 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
             for (int r = 0; r < 4; ++r)
                 cs[r] = o == 4 ? cs[r] + dpp_f32<0x124>(cs[r]) : o == 8 ? cs[r] + dpp_f32<0x128>(cs[r]) : o == 16 ? xor16_sum(cs[r]) : xor32_sum(cs[r]);
         }
-        if (lane < LPR) {
+        if (lane < LPR && nok) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + n + r, cs[r]);
         }
@@ -729,7 +736,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // code resident).
 template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, bool FAST = false, unsigned EPI = 0>
 __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_linear) {
-    static_assert(EPI == 0 || FAST, "specialised epilogues assume whole tiles");
     constexpr int NW = WM_ * WN_;
     constexpr int WTM = BM / WM_, WTN = BN / WN_, TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -1025,7 +1031,7 @@ constexpr int MAX_GROUP = 32;
 struct GroupItem { const h16_t* a; const h16_t* b; float* c; int M, N, K, lda, ldb, ldc, tiles_n; unsigned tiles_n_magic; };
 struct GroupArgs { int n; int k_rotate; float* sumsq; int tile_end[MAX_GROUP]; GroupItem it[MAX_GROUP]; };
 
-template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC>
+template <int BM, int BN, int WM_, int WN_, int BKT, int STAGES1, bool A_KC, bool B_KC, unsigned EPI = 0>
 __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const GroupArgs g) {
     // one tile per workgroup (the persistent form `for (tt = blockIdx.x; tt < total; tt += gridDim.x)` of rounds 1-2 is an A/B build only: see
     // gemm_v1_kernel for what the loop cost every launch)
@@ -1048,7 +1054,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void gemm_v1_grouped_kernel(const G
         p.k_per_split = (it.K + BKT - 1) / BKT * BKT;
         p.k_rotate = g.k_rotate;
         p.sumsq = g.sumsq;
-        gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC>(p, t - (i ? g.tile_end[i - 1] : 0));
+        gemm_v1_body<BM, BN, WM_, WN_, BKT, STAGES1, A_KC, B_KC, false, EPI>(p, t - (i ? g.tile_end[i - 1] : 0));
 #ifdef VQA_GEMM_PERSIST
         __syncthreads();                                     // the ring (epilogue scratch) is free again
 #endif
@@ -1310,6 +1316,8 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
                 if constexpr (BM == 64 && BN == 64 && ST == 3 && AK && BKC) {
                     VQA_EPI(true, ACT_NONE, false, ACT_NONE, true, true, true, false, false);          // out_proj / fc2 forward, text tower (hidden dropout)
                     VQA_EPI(true, ACT_NONE, false, ACT_NONE, false, true, true, false, false);         // out_proj / fc2 forward, vision tower
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, false, false, false, true, false);        // projections to 16-bit (generative decoder: cross-attention q)
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, false, true, false, false);       // patch embedding
                 }
                 if constexpr (BM == 64 && BN == 64 && ST == 3 && AK && !BKC) {
                     VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, true, true, false, false);        // input gradient + the residual stream's gradient
@@ -1319,10 +1327,27 @@ int launch_v1k(const GemmArgs& p, int splits, hipStream_t st) {
                 if constexpr (BM == 128 && BN == 64 && ST == 2 && AK && BKC) {
                     VQA_EPI(true, ACT_GELU_ERF, true, ACT_NONE, false, false, false, true, false);     // fc1 forward, text tower
                     VQA_EPI(true, ACT_QUICK_GELU, true, ACT_NONE, false, false, false, true, false);   // fc1 forward, vision tower
+                    VQA_EPI(true, ACT_GELU_ERF, true, ACT_NONE, true, false, false, true, false);      // generative fusion / decoder: linear1 + GELU + dropout
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, false, false, false, true, false);        // packed in-projections to 16-bit
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, false, true, false, false);       // the 64 000-way output projection
                 }
                 if constexpr (BM == 128 && BN == 64 && ST == 2 && AK && !BKC) {
                     VQA_EPI(false, ACT_NONE, false, ACT_GELU_ERF, false, false, false, true, true);    // fc2 input gradient x GELU'(z), + fc1's bias gradient
                     VQA_EPI(false, ACT_NONE, false, ACT_QUICK_GELU, false, false, false, true, true);
+                    VQA_EPI(false, ACT_NONE, false, ACT_GELU_ERF, true, false, false, true, true);     // ... through the dropout of the generative layers
+                }
+                // one-token-per-sample launches (experts, answer head): 32 x 32 tiles
+                if constexpr (BM == 32 && BN == 32 && ST == 3 && AK && BKC) {
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, true, true, true, false, false);
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, false, false, false, true, false);
+                    VQA_EPI(true, ACT_GELU_ERF, true, ACT_NONE, true, false, false, true, false);
+                    VQA_EPI(true, ACT_NONE, false, ACT_NONE, false, false, true, false, false);
+                }
+                if constexpr (BM == 32 && BN == 32 && ST == 3 && AK && !BKC) {
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, true, true, false, false);
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, false, true, false, false);
+                    VQA_EPI(false, ACT_NONE, false, ACT_NONE, false, false, false, true, false);
+                    VQA_EPI(false, ACT_NONE, false, ACT_GELU_ERF, true, false, false, true, true);
                 }
             }
 #undef VQA_EPI
@@ -1632,10 +1657,14 @@ int g_group_persistent = 0; // > 0: grouped launches run persistent on at most t
 template <int BM, int BN, int ST, bool AK, bool BKC, int WM_ = 2, int WN_ = 2>
 static int launch_grouped(const GroupArgs& g, hipStream_t st) {
     constexpr int LDS = ST * (BM + BN) * 64 * 2;
-    auto kern = gemm_v1_grouped_kernel<BM, BN, WM_, WN_, 64, ST, AK, BKC>;
+    // a grouped launch stores fp32 outputs and nothing else (+ the fused sum of squares): always the compile-time epilogue (gemm_epilogue_s) -- with
+    // the experts' 32-token reductions the epilogue IS the kernel (one k-step against 16 row batches of a 128 x 128 tile)
+    constexpr unsigned E0 = epi_make(false, ACT_NONE, false, ACT_NONE, false, false, true, false, false, false), E1 = E0 | E_SUMSQ;
+    auto kern = g.sumsq ? gemm_v1_grouped_kernel<BM, BN, WM_, WN_, 64, ST, AK, BKC, E1> : gemm_v1_grouped_kernel<BM, BN, WM_, WN_, 64, ST, AK, BKC, E0>;
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v1_grouped_kernel<BM, BN, WM_, WN_, 64, ST, AK, BKC, E0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v1_grouped_kernel<BM, BN, WM_, WN_, 64, ST, AK, BKC, E1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
