@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out
-timeout -k 10 300 python scratch/gemm_census.py cfg3_mcan_moe4 > $O/census_cfg3.log 2>&1 || { tail -5 $O/census_cfg3.log; exit 1; }
-timeout -k 10 300 python scratch/gemm_census.py generative > $O/census_gen.log 2>&1 || { tail -5 $O/census_gen.log; exit 1; }
+timeout -k 10 200 python scratch/epi_diff.py > $O/epi_diff.log 2>&1; tail -12 $O/epi_diff.log
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -q -x -p no:cacheprovider -k "gemm or compact or grouped or specialised" > $O/fast_tests.log 2>&1; tail -3 $O/fast_tests.log

@@ -83,34 +83,48 @@ __device__ __forceinline__ float wave_max(float v) {
 // t = 1 / (1 + 0.3275911 z), |error| <= 1.5e-7 -- three orders below the bf16 rounding of every value these feed, and a
 // third of the instructions of libm's erff (one v_exp_f32, one v_rcp_f32, six FMAs).  The SAME exp(-x^2/2) is the Gaussian
 // density the derivative needs, so backward costs no second exponential.
+// The arithmetic of these three functions is spelled out -- explicit FMAs, fp contraction OFF for everything else -- so that a value is a pure
+// function of its argument wherever the function is inlined.  Left to the compiler's contraction the SAME source gave results one fp32 rounding
+// apart in two epilogues of the same GEMM (x * (1 - h) became fma(-h, x, x) in one context and not in the other: round 3, found when the
+// compile-time epilogue forms were compared bit for bit with the generic one).
 struct GeluParts { float cdf, e; };      // cdf = Phi(x);  e = exp(-x*x/2)
 __device__ __forceinline__ GeluParts gelu_parts(float x) {
-    const float ax = fabsf(x), z = ax * 0.70710678118654752440f;
-    const float e = __expf(-z * z);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float half_erfc = 0.5f * poly * e;                    // 0.5 * (1 - erf(z))
-    return {x >= 0.f ? 1.0f - half_erfc : half_erfc, e};
+#pragma clang fp contract(off)
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float zz = z * z;
+    const float e = __expf(-zz);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    poly = t * poly;
+    const float half_erfc = (0.5f * poly) * e;                  // 0.5 * (1 - erf(z))
+    const float upper = 1.0f - half_erfc;
+    return {x >= 0.f ? upper : half_erfc, e};
 }
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
+#pragma clang fp contract(off)
     switch (act) {
-        case ACT_GELU_ERF: return x * gelu_parts(x).cdf;
-        case ACT_QUICK_GELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+        case ACT_GELU_ERF: { const float c = gelu_parts(x).cdf; return x * c; }
+        case ACT_QUICK_GELU: { const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); return x * s; }
         case ACT_RELU: return x > 0.f ? x : 0.f;
         default: return x;
     }
 }
 // d act(x) / dx
 __device__ __forceinline__ float act_bwd(float x, int act) {
+#pragma clang fp contract(off)
     switch (act) {
         case ACT_GELU_ERF: {
             const GeluParts g = gelu_parts(x);
-            return g.cdf + x * 0.39894228040143267794f * g.e;
+            return __builtin_fmaf(x * 0.39894228040143267794f, g.e, g.cdf);
         }
         case ACT_QUICK_GELU: {
             const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
-            return s * (1.0f + 1.702f * x * (1.0f - s));
+            const float w = (1.702f * x) * (1.0f - s);
+            return s * (1.0f + w);
         }
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
         default: return 1.f;

@@ -859,7 +859,9 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
 #ifdef VQA_GEMM_TRACE
                 if (kt < 24) VQA_T(2 + kt);
 #endif
+#ifndef VQA_DMA_AFTER_READS
                 if (kt + STAGES1 - 1 < nk) issue(kt + STAGES1 - 1, (s + STAGES1 - 1) % STAGES1);
+#endif
                 const char* la = smem + s * STAGE_BYTES;
                 const char* lb = la + A_BYTES;
 #pragma unroll
@@ -869,6 +871,9 @@ __device__ __forceinline__ void gemm_v1_body(const GemmArgs& p, const int tile_l
                     for (int i = 0; i < TM; ++i) fa[i] = load_frag1_asm<BM, A_KC>(la, ao0[i], ao1[i], ks);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[j] = load_frag1_asm<BN, B_KC>(lb, bo0[j], bo1[j], ks);
+#ifdef VQA_DMA_AFTER_READS      // A/B build: the refill of the ring is issued under the LDS round trip of the first fragment reads
+                    if (ks == 0 && kt + STAGES1 - 1 < nk) issue(kt + STAGES1 - 1, (s + STAGES1 - 1) % STAGES1);
+#endif
 #ifdef VQA_KC_PLAIN_READS
                     frag_fence<!A_KC || !B_KC>(fa, fb);
 #else
