@@ -67,13 +67,16 @@ int vqa_gemm_bf16(const VqaGemmDesc* d, vqa_stream_t stream);
  * weight-gradient GEMMs of a backward pass (dW = dY^T X: a_kc = b_kc = 0), which nothing but the optimiser waits for and
  * which the block runners therefore queue and issue together -- one cold start and one tail for all of them, thousands of
  * equal tiles to balance over the CUs.  Same tile kernel and numerics as vqa_gemm_bf16 (64x64 LDS-DMA ring, no split-K). */
+#define VQA_SUMSQ_SLOTS 64      /* power of two */
+#define VQA_SUMSQ_STRIDE 32     /* floats: one 128-B line per slot */
 typedef struct VqaGemmGroupItem {
     const void* a; const void* b; float* c_f32;
     int M, N, K, lda, ldb, ldc;
 } VqaGemmGroupItem;
 int vqa_gemm_bf16_grouped(const VqaGemmGroupItem* items, int n, int a_kc, int b_kc, vqa_stream_t s);   /* a_kc == b_kc */
-/* The same with the optimiser's global-norm reduction riding along: sumsq (optional device fp32 scalar, caller-initialised) += the sum of
- * squares of every value written to the outputs (torch.nn.utils.clip_grad_norm_, training_pipeline.py:497, needs exactly this over all
+/* The same with the optimiser's global-norm reduction riding along: sumsq (optional; VQA_SUMSQ_SLOTS partial accumulators VQA_SUMSQ_STRIDE floats apart,
+ * caller-initialised: their SUM is the quantity -- thousands of workgroups adding to ONE address finish together and serialise in one L2
+ * channel: 173 us for a 33-us launch, round 3) += the sum of squares of every value written to the outputs (torch.nn.utils.clip_grad_norm_, training_pipeline.py:497, needs exactly this over all
  * gradients: the weight gradients' share is taken where they are produced instead of re-reading 4 B per parameter).  Weight-gradient items
  * (a_kc == b_kc == 0) whose rows / columns are multiples of 256 and whose token count is a multiple of 64 run on 256 x 256 tiles, one
  * 8-wave workgroup per CU (csrc/gemm_dw256.h): up to 64 of them per launch, longest reduction first, tiles drawn from a ticket counter

@@ -961,14 +961,16 @@ def test_grouped_weight_gradients_on_256_tiles_are_exact_and_carry_their_sum_of_
                 keep += [dy_full, dy, x]
                 outs.append(out)
                 refs.append(dy.float().t() @ x.float())
-            ssq = torch.zeros(1, device=DEV)
+            ssq = torch.zeros(hl.SUMSQ_SLOTS * hl.SUMSQ_STRIDE, device=DEV)      # slotted partial sums: their sum is the quantity
             rc = L.vqa_gemm_bf16_grouped2(items, len(cases), 0, 0, ssq.data_ptr(), torch.cuda.current_stream().cuda_stream)
             assert rc == 0
             torch.cuda.synchronize()
             for c, o, r in zip(cases, outs, refs):
                 assert torch.equal(o, r), (big, c, float((o - r).abs().max()))
             want = sum(float((r.double() ** 2).sum()) for r in refs)
-            assert abs(float(ssq) - want) <= 1e-5 * want, (big, float(ssq), want)
+            got = float(ssq.double().sum())
+            assert abs(got - want) <= 1e-5 * want, (big, got, want)
+            assert int((ssq.view(hl.SUMSQ_SLOTS, hl.SUMSQ_STRIDE)[:, 1:] != 0).sum()) == 0      # only the first float of each slot is used
     finally:
         L.vqa_set_gemm_dw256(1)
     # real-valued data: the two kernels agree to fp32 summation-order noise

@@ -371,7 +371,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
     VQA_ET(3);
     if (p.sumsq) {
         ssq = wave_sum(ssq);
-        if (lane == 0) atomicAdd(p.sumsq, ssq);
+        if (lane == 0) atomicAdd(p.sumsq + ((blockIdx.x & (VQA_SUMSQ_SLOTS - 1)) * VQA_SUMSQ_STRIDE), ssq);      // slotted: see include/vqa_hip.h
     }
     if (p.colsum) {
         // lanes l, l + LPR, l + 2 LPR ... hold the same 4 columns: fold them, then ONE lane per column group adds
@@ -509,7 +509,7 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
     }
     if (SSQ) {
         ssq = wave_sum(ssq);
-        if (lane == 0) atomicAdd(p.sumsq, ssq);
+        if (lane == 0) atomicAdd(p.sumsq + ((blockIdx.x & (VQA_SUMSQ_SLOTS - 1)) * VQA_SUMSQ_STRIDE), ssq);      // slotted: see include/vqa_hip.h
     }
     if (CS) {
 #pragma unroll

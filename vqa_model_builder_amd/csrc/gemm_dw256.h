@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_dw256_tile(const DwTile& T, int m0, int n0,
         }
         if (sumsq) {
             ssq = wave_sum(ssq);
-            if (lane == 0) atomicAdd(sumsq, ssq);
+            if (lane == 0) atomicAdd(sumsq + ((blockIdx.x & (VQA_SUMSQ_SLOTS - 1)) * VQA_SUMSQ_STRIDE), ssq);
         }
     }
     DW_STAMP(12);

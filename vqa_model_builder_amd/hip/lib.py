@@ -158,6 +158,9 @@ def set_half(kind: str):
     return load()
 
 
+SUMSQ_SLOTS, SUMSQ_STRIDE = 64, 32      # include/vqa_hip.h: VQA_SUMSQ_SLOTS / VQA_SUMSQ_STRIDE (vqa_gemm_bf16_grouped2's partial accumulators)
+
+
 def load(path: str = None):
     """Loads the shared library of the active operand type and types every entry point.  Raises HipLibraryMissing if it
     is not built."""

@@ -14,6 +14,7 @@ import struct
 import torch
 
 from .hip import kernels as K
+from .hip import lib as _hl
 from .hip import ops as _ops
 from .hip import shadow as _shadow
 
@@ -58,7 +59,7 @@ class FusedAdamW(torch.optim.Optimizer):
         the reduced gradients').  ``GraphedTrainStep`` switches it on for its single-GPU step."""
         if on:
             dev = torch.device(device) if device is not None else next((p.device for g in self.param_groups for p in g['params']), None)
-            self._wnorm2 = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._wnorm2 = torch.zeros(_hl.SUMSQ_SLOTS * _hl.SUMSQ_STRIDE, dtype=torch.float32, device=dev)      # slotted partial sums (include/vqa_hip.h)
             K.WGRAD_SUMSQ, K.WGRAD_SUMSQ_COVERED = self._wnorm2, []
         else:
             if K.WGRAD_SUMSQ is self._wnorm2:
@@ -304,7 +305,7 @@ class FusedAdamW(torch.optim.Optimizer):
             amp = self._amp_state(dev)
         if clip or amp is not None:
             if in_gemm is not None:
-                self._norm2.copy_(self._wnorm2)            # the weight gradients' share, summed by the GEMMs that stored them
+                torch.sum(self._wnorm2, dim=0, keepdim=True, out=self._norm2)      # the weight gradients' share, summed by the GEMMs that stored them
             else:
                 self._norm2.zero_()
             for _, _, tab, chunks, nch, _, nrm, nnrm in tables:
@@ -345,6 +346,17 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in standalone:
             _ops.mark_shadow_fresh(p)
         return loss
+
+    def norm_coverage(self):
+        """(elements the clipping norm's own pass reads, elements of all gradients) of the last step's job tables: with the weight gradients' sum of
+        squares taken in their GEMMs (fuse_wgrad_norm) the first number is what is left -- embedding tables, biases, LayerNorm affine."""
+        ch = _hl.load().vqa_opt_chunk_elems()
+        read = total = 0
+        for key, rows, chunks, nch, nrm, nnrm in self._tables.values():
+            n = sum(r[5] for r in key[0])
+            total += n
+            read += n if nnrm == nch else sum(min(ch, key[0][ji][5] - off) for ji, off in (nrm.tolist() if nrm is not None else []))
+        return read, total
 
     def grad_norm(self):
         """Global gradient norm of the last clipped step (device scalar)."""
