@@ -59,6 +59,11 @@ def test_weight_gradient_norm_taken_in_the_gemms_equals_the_norm_pass():
                     opt.step()
                     got = float(opt.grad_norm())
                     assert abs(got - want) <= 1e-5 * want, (fused, step, got, want)
+                    read, total = opt.norm_coverage()
+                    # fused: the optimiser's own pass must really have shrunk to what no GEMM wrote (embedding tables, biases, LayerNorm affine);
+                    # a silent fall-back to the full pass gives the right norm too (round 3: packed in-projection gradients written by two
+                    # GEMMs made the byte bookkeeping miss and every step fell back)
+                    assert (read < 0.6 * total) if fused else (read == total), (fused, step, read, total)
                     if step == 0:
                         first.append((got, [p.detach().clone() for p in model.parameters()]))
             finally:

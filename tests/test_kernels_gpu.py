@@ -710,7 +710,7 @@ def test_grouped_weight_gradient_gemm_matches_single_launches():
     (same tile kernel, same k order), on ragged token counts and mixed output shapes."""
     from vqa_model_builder_amd.hip import kernels as K
     torch.manual_seed(3)
-    shapes = [(2048, 768, 768), (2048, 2304, 768), (1600, 768, 3072), (200, 64, 128), (72, 136, 72)]
+    shapes = [(2048, 768, 768), (2048, 2304, 768), (1600, 768, 3072), (200, 64, 128), (72, 136, 72), (50, 72, 136), (15, 64, 40)]
     dys = [torch.randn(m, n, device='cuda').to(torch.bfloat16) for m, n, k in shapes]
     xs = [torch.randn(m, k, device='cuda').to(torch.bfloat16) for m, n, k in shapes]
     prev = K.WGRAD_GROUPED
@@ -944,7 +944,7 @@ def test_grouped_weight_gradients_on_256_tiles_are_exact_and_carry_their_sum_of_
         return torch.randint(-3, 4, shape, generator=g).float().to(DEV).to(BF)
     # (tokens, out rows, in columns): eligible and not
     cases = [(2048, 768, 768), (1600, 2304, 768), (2048, 768, 3072), (64, 256, 256), (192, 512, 256), (320, 256, 768), (2048, 512, 768), (1600, 768, 200),
-             (96, 256, 256), (128, 3000, 512)]
+             (96, 256, 256), (128, 3000, 512), (15, 64, 192), (50, 768, 256), (1, 256, 256)]        # ... and token counts that are no multiple of anything
     try:
         for big in (1, 0):
             L.vqa_set_gemm_dw256(big)

@@ -296,7 +296,7 @@ def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=
         out = torch.empty((N, K), dtype=F32, device=dy_bf16.device)
         gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=False)
         return out
-    if WGRAD_GROUPED and out.stride(-1) == 1 and M % 8 == 0 and N % 8 == 0 and K % 8 == 0:
+    if WGRAD_GROUPED and out.stride(-1) == 1 and N % 8 == 0 and K % 8 == 0:        # any token count M: the reduction's ragged tail is zero-filled per lane
         _, slot = _wgrad_slot()
         slot[2].append((dy_bf16, x_bf16, M, N, K, ldy or N, ldx or K, out, prezeroed))
         return out

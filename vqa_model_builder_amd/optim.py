@@ -82,6 +82,13 @@ class FusedAdamW(torch.optim.Optimizer):
         spans = sorted(set(K.WGRAD_SUMSQ_COVERED))
         if len(spans) != len(K.WGRAD_SUMSQ_COVERED) or any(a[1] > b[0] for a, b in zip(spans, spans[1:])):
             return None                                    # a range written twice (two backward passes since zero_grad) or overlapping ranges
+        merged = []                                       # ranges that touch are one range: a packed gradient (q | k | v rows of an in-projection)
+        for a, e in spans:                                # may be written by two GEMMs, each covering its rows
+            if merged and merged[-1][1] == a:
+                merged[-1][1] = e
+            else:
+                merged.append([a, e])
+        spans = [(a, e) for a, e in merged]
         starts = [a for a, _ in spans]
         counted, nbytes = set(), 0
         for pid, a, e in grads:
