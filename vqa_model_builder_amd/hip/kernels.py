@@ -216,8 +216,11 @@ def _launch_group(pending):
     fused = WGRAD_SUMSQ is not None and WGRAD_SUMSQ_COVERED is not None
     groups = [(pending, None)]
     if fused:
-        ok = [a for a in pending if a[7].is_contiguous()]
-        groups = [(ok, WGRAD_SUMSQ), ([a for a in pending if not a[7].is_contiguous()], None)]
+        # ... and rows written into a ZERO-FILLED slot (prezeroed: the v rows of a one-key attention's packed in-projection, whose q / k rows keep
+        # the exact zero the reference gives them) are part of a gradient nobody else writes: counted here, the optimiser would find a range
+        # that covers a third of a gradient and fall back to its full pass for the WHOLE model (round 3: every MoE config did)
+        ok = [a for a in pending if a[7].is_contiguous() and not a[8]]
+        groups = [(ok, WGRAD_SUMSQ), ([a for a in pending if not (a[7].is_contiguous() and not a[8])], None)]
     for todo, ssq in groups:
         for i0 in range(0, len(todo), WGRAD_GROUP_MAX):
             chunk = todo[i0:i0 + WGRAD_GROUP_MAX]
