@@ -88,6 +88,8 @@ class GraphedTrainStep:
             # single GPU: the clipping norm's weight-gradient share is summed by the GEMMs that store those gradients (one backward per step
             # here, nothing all-reduced behind it): -0.98 GB of re-reads per cfg2 step
             optimizer.fuse_wgrad_norm(True, dev)
+        elif hasattr(optimizer, 'fuse_wgrad_norm'):
+            optimizer.fuse_wgrad_norm(False)                # data parallel: the norm must be the all-reduced gradients'
         can_segment = hasattr(model, 'encode_both') and hasattr(model, 'forward_from_features')
         if segmented is None:
             segmented = reducer is not None and not getattr(reducer, 'single', True) and can_segment

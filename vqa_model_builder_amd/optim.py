@@ -62,8 +62,9 @@ class FusedAdamW(torch.optim.Optimizer):
             self._wnorm2 = torch.zeros(_hl.SUMSQ_SLOTS * _hl.SUMSQ_STRIDE, dtype=torch.float32, device=dev)      # slotted partial sums (include/vqa_hip.h)
             K.WGRAD_SUMSQ, K.WGRAD_SUMSQ_COVERED = self._wnorm2, []
         else:
-            if K.WGRAD_SUMSQ is self._wnorm2:
-                K.WGRAD_SUMSQ, K.WGRAD_SUMSQ_COVERED = None, None
+            # also when the accumulators are ANOTHER optimiser's (an earlier model of this process): the GEMMs of the step being built must not
+            # keep adding to a buffer nobody reads; that optimiser then finds the global gone and takes its full norm pass (always correct)
+            K.WGRAD_SUMSQ, K.WGRAD_SUMSQ_COVERED = None, None
             self._wnorm2 = None
         return self
 
