@@ -7,33 +7,55 @@
 namespace {
 
 // out[m,n] = bf16(dy[m,n] * act'(pre[m,n]) * keep(m*N+n));  colsum[n] += sum_m out  (the bias gradient; pre-zeroed slot).
-// Thread = 4 consecutive columns x a chunk of `rpc` rows (32 for the experts' few rows; 8 when M is in the thousands, so that the grid
-// is thousands of waves instead of a few hundred latency-bound ones: 3648 x 768 took 17.5 us with 32-row chunks).
-__global__ __launch_bounds__(64) void rows_mask_cast_kernel(const float* __restrict__ dy, int ld, const h16_t* __restrict__ pre, int act,
-                                                            h16_t* __restrict__ outb, float* __restrict__ colsum, int M, int N, float p, float inv_keep,
-                                                            uint64_t seed, uint32_t stream, int rpc) {
-    const int c4 = blockIdx.x * 64 + threadIdx.x;
-    if (c4 * 4 >= N) return;
+// Workgroup = 4 waves: lane -> 4 consecutive columns of a 256-column panel, wave w -> rows m0 + w, m0 + w + 4, ... of an RPB-row chunk, RPW rows
+// per wave with ALL their loads issued before the first use (the first form walked 8 rows per thread one dependent load at a time and added
+// every thread's column sums with its own atomics: 3648 x 768 took 23 us -- 350 000 atomics on 768 addresses -- and was 5 % of the generative
+// model's step); the four waves' column sums meet in LDS and leave as ONE atomic per column and workgroup.
+template <int RPW>
+__global__ __launch_bounds__(256) void rows_mask_cast_kernel(const float* __restrict__ dy, int ld, const h16_t* __restrict__ pre, int act,
+                                                             h16_t* __restrict__ outb, float* __restrict__ colsum, int M, int N, float p, float inv_keep,
+                                                             uint64_t seed, uint32_t stream) {
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    const bool cok = c4 * 4 < N;
     if (p > 0.f) seed = resolve_seed(seed);
-    const int m0 = blockIdx.y * rpc, m1 = min(M, m0 + rpc);
+    const int m0 = blockIdx.y * (4 * RPW) + wave;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int m = m0; m < m1; ++m) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(dy + (size_t)m * ld + 4 * c4);
-        if (pre) {
-            const h16x4 pv = *reinterpret_cast<const h16x4*>(pre + (size_t)m * N + 4 * c4);
+    if (cok) {
+        f32x4 v[RPW];
+        h16x4 pv[RPW];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= act_bwd((float)pv[r], act);
+        for (int i = 0; i < RPW; ++i) {
+            const int m = min(m0 + 4 * i, M - 1);                        // clamped rows are loaded and dropped
+            v[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)m * ld + 4 * c4);
+            if (pre) pv[i] = *reinterpret_cast<const h16x4*>(pre + (size_t)m * N + 4 * c4);
         }
-        if (p > 0.f) v *= dropout_scale4(seed, stream, (uint64_t)m * N + 4 * c4, p, inv_keep);
-        h16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { o[r] = (h16_t)v[r]; acc[r] += (float)o[r]; }
-        *reinterpret_cast<h16x4*>(outb + (size_t)m * N + 4 * c4) = o;
+        for (int i = 0; i < RPW; ++i) {
+            const int m = m0 + 4 * i;
+            if (m < M) {
+                f32x4 x = v[i];
+                if (pre) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] *= act_bwd((float)pv[i][r], act);
+                }
+                if (p > 0.f) x *= dropout_scale4(seed, stream, (uint64_t)m * N + 4 * c4, p, inv_keep);
+                h16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o[r] = (h16_t)x[r]; acc[r] += (float)o[r]; }
+                *reinterpret_cast<h16x4*>(outb + (size_t)m * N + 4 * c4) = o;
+            }
+        }
     }
     if (colsum) {
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && cok) {
+            const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(colsum + 4 * c4 + r, acc[r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(colsum + 4 * c4 + r, t[r]);
+        }
     }
 }
 
@@ -231,9 +253,15 @@ int vqa_rows_mask_cast(const float* dy, int ld, const void* pre_bf16, int act, v
                        uint64_t seed, uint32_t stream, vqa_stream_t s) {
     if (!dy || !out_bf16 || M <= 0 || N <= 0 || N % 4 || ld % 4 || p < 0.f || p >= 1.f) return VQA_ERR_ARG;
     if (((uintptr_t)dy & 15) || ((uintptr_t)out_bf16 & 7) || (pre_bf16 && ((uintptr_t)pre_bf16 & 7))) return VQA_ERR_ARG;
-    const int rpc = M > 512 ? 8 : 32;
-    hipLaunchKernelGGL(rows_mask_cast_kernel, dim3(ceil_div(N / 4, 64), ceil_div(M, rpc)), dim3(64), 0, (hipStream_t)s, dy, ld, (const h16_t*)pre_bf16, act,
-                       (h16_t*)out_bf16, colsum, M, N, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, stream, rpc);
+    // rows per workgroup: 32 (8 per wave) once that still gives every CU a workgroup, else 16 / 8 (the experts' few rows: 4 x 2)
+    const int cols = ceil_div(N / 4, 64);
+    const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
+#define VQA_RMC(RPW) hipLaunchKernelGGL((rows_mask_cast_kernel<RPW>), dim3(cols, ceil_div(M, 4 * RPW)), dim3(256), 0, (hipStream_t)s, dy, ld, (const h16_t*)pre_bf16, act, \
+                                        (h16_t*)out_bf16, colsum, M, N, p, ik, seed, stream)
+    if ((long)cols * ceil_div(M, 32) >= 256) VQA_RMC(8);
+    else if ((long)cols * ceil_div(M, 16) >= 128) VQA_RMC(4);
+    else VQA_RMC(2);
+#undef VQA_RMC
     return (int)hipGetLastError();
 }
 

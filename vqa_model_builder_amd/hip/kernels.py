@@ -291,7 +291,8 @@ class skip_weight_grads:
 
 def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
     """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path).  ``prezeroed``: ``out``
-    is known to be zero (gradient arena), so a split-K launch needs no memset.  With WGRAD_GROUPED (default) and a
+    is known to be zero (gradient arena), so a split-K launch needs no memset (truthy values also keep the output out of the fused
+    clipping norm: rows of a zero-filled slot are part of a gradient nobody else writes; 2 = "not zeroed, but do not count").  With WGRAD_GROUPED (default) and a
     caller-provided ``out`` the GEMM is only queued: the caller must end its backward with wgrad_join()."""
     if SKIP_WEIGHT_GRADS and out is not None:
         return out                                      # frozen block: nobody reads this gradient
@@ -303,7 +304,7 @@ def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=
         _, slot = _wgrad_slot()
         slot[2].append((dy_bf16, x_bf16, M, N, K, ldy or N, ldx or K, out, prezeroed))
         return out
-    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed)
+    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed is True or prezeroed == 1)
     return out
 
 

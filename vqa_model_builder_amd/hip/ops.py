@@ -406,7 +406,12 @@ class _LinearCEFn(torch.autograd.Function):
             if xdtype != F32:
                 dx = dx.to(xdtype)
         if ctx.needs_input_grad[1]:
-            dw = K.linear_dw(dlb, xb, M, V, D)
+            # through the grouped entry (the 64 000 x 768 output runs on the 256 x 256 weight-gradient tiles: 224 -> ~110 us), issued at once:
+            # autograd may SUM this tensor with another gradient of a tied weight (the generative model's token embedding) as soon as it is
+            # returned -- which is also why the fused clipping norm must not count it (flag 2)
+            dw = torch.empty((V, D), dtype=F32, device=xb.device)
+            K.linear_dw(dlb, xb, M, V, D, out=dw, prezeroed=2)
+            K.wgrad_flush()
         return dx, dw, None, None
 
 
