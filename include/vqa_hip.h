@@ -342,6 +342,12 @@ typedef struct VqaOptJob {
     const float* own_step;   /* optional device word: this job's OWN step count (number of updates it received, this one included)
                               * for the two bias corrections -- torch keeps `step` per parameter, so an expert skipped in some
                               * steps must not have its corrections aged by them.  Advanced by vqa_opt_advance_counts. */
+    uint8_t* touched;        /* optional device map, one byte per 256 elements (ceil(n / 256) bytes, zero = this granule's moments are still
+                              * exactly zero): a granule whose gradient is all zero in this step and whose byte is zero gets the update AdamW
+                              * gives it anyway -- p *= 1 - lr * weight_decay, moments stay zero -- WITHOUT reading or writing the moments (12
+                              * instead of 28 B per parameter); any non-zero gradient value sets the byte for good.  For embedding tables: of
+                              * PhoBERT's 64 001 rows a step touches at most batch x seq, most of the vocabulary never.  Decided from the
+                              * gradient VALUES, so any training flow stays exact; the caller owns the map (zero-filled when the moments are). */
 } VqaOptJob;
 /* chunks_dev: uint32 [nchunks][2] = {job index, first element}; every chunk covers vqa_opt_chunk_elems() elements of its
  * tensor (the last one of a tensor fewer): one workgroup per chunk keeps the chip streaming whatever the tensor sizes. */

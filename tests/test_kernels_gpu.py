@@ -1181,3 +1181,49 @@ def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
         L.vqa_set_gemm_v1_fast(1)
         L.vqa_set_gemm_k_rotate(0)
         K._k_rotate_state = None
+
+
+def test_fused_adamw_skips_the_moments_of_untouched_embedding_rows_exactly():
+    """VqaOptJob::touched (optim.FusedAdamW._touched_map): for a parameter the model marks ``_vqa_sparse_rows`` the update kernel leaves the
+    moments of a 256-element granule alone while they are exactly zero and the granule's gradient is all zero (what AdamW computes there
+    anyway: p *= 1 - lr * wd).  Against the same optimiser with the map switched off: parameters and both moments IDENTICAL TO THE BIT after
+    every step -- rows that never get a gradient, rows that get one later, rows that get one once and never again, a granule that straddles
+    two rows (row length 192), gradient clipping on and off, a state_dict round trip in the middle -- and equal to torch.optim.AdamW."""
+    from vqa_model_builder_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    V, D = 3000, 192
+    w0 = torch.randn(V, D, device=DEV)
+    other0 = torch.randn(50, 7, device=DEV)
+
+    def make(sparse):
+        w, o = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(other0.clone())
+        w._vqa_sparse_rows = True
+        opt = FusedAdamW([{'params': [w], 'weight_decay': 0.01}, {'params': [o], 'weight_decay': 0.0}], lr=1e-2, max_grad_norm=1.0)
+        opt.sparse_row_updates = sparse
+        return w, o, opt
+    wa, oa, opt_a = make(True)
+    wb, ob, opt_b = make(False)
+    wr, orf = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(other0.clone())
+    opt_r = torch.optim.AdamW([{'params': [wr], 'weight_decay': 0.01}, {'params': [orf], 'weight_decay': 0.0}], lr=1e-2)
+    g = torch.Generator().manual_seed(1)
+    for step in range(8):
+        if step == 4:                                      # checkpoint round trip: the map is rebuilt from the loaded moments
+            sd = opt_a.state_dict()
+            opt_a.load_state_dict(sd)
+        ids = torch.randint(0, 40 if step < 3 else 400, (64,), generator=g).to(DEV)      # later steps touch rows the first ones left alone
+        rows = torch.randn(64, D, generator=g).to(DEV) * (5.0 if step % 2 else 0.05)       # clipped / not clipped
+        gw = torch.zeros(V, D, device=DEV).index_add_(0, ids, rows)
+        go = torch.randn(50, 7, generator=g).to(DEV)
+        for w, o in ((wa, oa), (wb, ob), (wr, orf)):
+            w.grad, o.grad = gw.clone(), go.clone()
+        torch.nn.utils.clip_grad_norm_([wr, orf], 1.0)
+        opt_a.step(); opt_b.step(); opt_r.step()
+        assert torch.equal(wa, wb) and torch.equal(oa, ob), step
+        for k in ('exp_avg', 'exp_avg_sq'):
+            assert torch.equal(opt_a.state[wa][k], opt_b.state[wb][k]), (step, k)
+        assert torch.allclose(wa, wr, atol=1e-6, rtol=1e-5)
+    touched = opt_a._touched[id(wa)][0]
+    frac = float(touched.float().mean())
+    assert 0.02 < frac < 0.4, frac                         # the map really is sparse: most granules never saw a gradient
+    never = (opt_a.state[wa]['exp_avg'].reshape(-1)[:touched.numel() * 256].view(-1, 256) != 0).any(1)
+    assert torch.equal(never, touched.bool())              # and it says exactly where the moments are non-zero

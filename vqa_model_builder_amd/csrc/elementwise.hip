@@ -317,6 +317,26 @@ __global__ void adamw_multi_kernel(const VqaOptJob* __restrict__ jobs, const uin
     for (uint64_t i = beg + 4 * threadIdx.x; i < e4; i += 4 * blockDim.x) {
         f32x4 p = VQA_LD4(j.param + i);
         const f32x4 g = (g16 ? wire_bf16x4(j.grad, i) : VQA_LD4(j.grad + i)) * gs;
+        if (j.touched) {
+            // One wave's 64 x 4 elements of an iteration are one 256-element granule (chunks start at multiples of 65536): a granule whose
+            // moments are still exactly zero (byte 0) and whose gradient is all zero now gets what the full update would give it -- p * decay
+            // - step_size * (0 / (0 + eps)) = p * decay, moments 0 -> 0 -- without touching the moments.  Wave-uniform, decided from values.
+            const uint64_t gran = i >> 8;
+            const bool nz = (g[0] != 0.f) | (g[1] != 0.f) | (g[2] != 0.f) | (g[3] != 0.f);
+            const bool any_nz = __builtin_amdgcn_ballot_w64(nz) != 0;
+            const bool was = j.touched[gran] != 0;
+            if (!was && !any_nz) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { p[k] *= decay; p[k] -= step_size * (0.f / (0.f * inv_sqrt_bc2 + eps)); }
+                VQA_ST4(j.param + i, p);
+                if (j.shadow) {
+                    if (skind == 0) { h16x4 o; for (int k = 0; k < 4; ++k) o[k] = (h16_t)p[k]; *reinterpret_cast<h16x4*>((h16_t*)j.shadow + i) = o; }
+                    else *reinterpret_cast<f32x4*>((float*)j.shadow + i) = p;
+                }
+                continue;
+            }
+            if (!was && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) j.touched[gran] = 1;
+        }
         f32x4 m = VQA_LD4(j.exp_avg + i);
         f32x4 v = VQA_LD4(j.exp_avg_sq + i);
 #pragma unroll

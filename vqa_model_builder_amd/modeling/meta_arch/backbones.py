@@ -235,6 +235,7 @@ class _RobertaEmbeddings(nn.Module):
     def __init__(self, V, D, max_pos, type_vocab, pad, eps):
         super().__init__()
         self.word_embeddings = nn.Embedding(V, D, padding_idx=pad)
+        self.word_embeddings.weight._vqa_sparse_rows = True      # FusedAdamW: a step's gradient is non-zero in <= batch x seq of the V rows (optim._touched_map)
         self.token_type_embeddings = nn.Embedding(type_vocab, D)
         self.LayerNorm = nn.LayerNorm(D, eps=eps)
         self.position_embeddings = nn.Embedding(max_pos, D, padding_idx=pad)   # registered last, as HF does (parameter order)

@@ -9,6 +9,7 @@ State layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter) matches tor
 are interchangeable.
 """
 
+import os
 import struct
 
 import torch
@@ -44,6 +45,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._hyper_key, self._epoch = [], 0              # class -> (group, step count at creation, step() call that created it)
         self._staging = {}                                # HIP-graph mode: pinned host rows per job table
         self._wnorm2 = None                               # fuse_wgrad_norm(): device scalar the weight-gradient GEMMs add their sum of squares to
+        self._touched = {}                                # id(parameter) -> (touched-granule map, the exp_avg it was built for): _touched_map()
+        self.sparse_row_updates = os.environ.get('VQA_SPARSE_ROWS', '1') != '0'      # False: every granule of every parameter takes the full update path (tests, A/B)
         self.grad_prescale = 1.0                          # DP: gradients hold the all-reduced SUM; 1/world is applied here
         self.wire_grads = None                            # DP captured step with bf16 buckets: id(parameter) -> device address of its all-reduced
                                                           # bfloat16 gradient in the exchange's staging buffer (read there: no copy back to fp32)
@@ -273,7 +276,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     ent[2].setdefault(e, prev_step)
                 launches.setdefault((gi, state['step']) if self._hyper is None else (gi, -1 - self._class_of(gi, p)), []).append(
                     (p.data_ptr(), gptr, state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(), sp, p.numel(), wd_kind,
-                     act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0, id(p)))
+                     act.data_ptr() if act is not None else 0, own.data_ptr() if own is not None else 0, self._touched_map(p, state), id(p)))
                 dev = p.device
         if not launches:
             return loss
@@ -284,8 +287,8 @@ class FusedAdamW(torch.optim.Optimizer):
         # weight gradients whose sum of squares the GEMMs that wrote them have already taken (fuse_wgrad_norm): left out of the norm pass below
         in_gemm = None if self.wire_grads else self._norm_counted(spans)
         for (gi, step), rows9 in launches.items():
-            rows = [r[:9] for r in rows9]
-            flags = tuple(in_gemm is not None and r[9] in in_gemm for r in rows9)
+            rows = [r[:10] for r in rows9]
+            flags = tuple(in_gemm is not None and r[10] in in_gemm for r in rows9)
             key = (tuple(rows), flags)
             slot = (gi, len(tables))
             live.add(slot)
@@ -354,6 +357,29 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in standalone:
             _ops.mark_shadow_fresh(p)
         return loss
+
+    def _touched_map(self, p, state):
+        """Device address of the parameter's touched-granule map (VqaOptJob::touched), or 0.  Only for parameters the model marks
+        ``_vqa_sparse_rows`` (embedding tables whose gradient is non-zero in a few rows per step): one byte per 256 elements, zero while the
+        granule's moments are exactly zero; the update kernel skips the moments' 16 B per parameter for granules with an all-zero gradient and
+        sets the byte at the first non-zero value.  Built from the moments themselves (a fresh state: all zero; a loaded checkpoint: where
+        they are non-zero), never part of ``state_dict()``."""
+        if not getattr(p, '_vqa_sparse_rows', False) or self.wire_grads or not self.sparse_row_updates:
+            return 0
+        t = self._touched.get(id(p))
+        if t is None or t[1] is not state['exp_avg']:
+            n, g = p.numel(), (p.numel() + 255) // 256
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('FusedAdamW: the touched-granule map of a sparse-row parameter must exist before a stream capture (run a warm-up step)')
+            nz = ((state['exp_avg'].reshape(-1) != 0) | (state['exp_avg_sq'].reshape(-1) != 0))
+            pad = torch.zeros(g * 256, dtype=torch.bool, device=p.device)
+            pad[:n] = nz
+            t = self._touched[id(p)] = (pad.view(g, 256).any(dim=1).to(torch.uint8).contiguous(), state['exp_avg'])
+        return t[0].data_ptr()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._touched.clear()                              # rebuilt from the loaded moments at the next step
 
     def norm_coverage(self):
         """(elements the clipping norm's own pass reads, elements of all gradients) of the last step's job tables: with the weight gradients' sum of
