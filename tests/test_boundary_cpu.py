@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     try:
         for kind, code in (('bf16', 0), ('fp16', 1)):      # both operand-type builds of the same sources export the same ABI
             l = lib.set_half(kind)          # types every entry point; AttributeError if one is missing
-            assert l.vqa_abi_version() == 5 and l.vqa_half_kind() == code
+            assert l.vqa_abi_version() == 6 and l.vqa_half_kind() == code
     finally:
         lib.set_half('bf16')
 

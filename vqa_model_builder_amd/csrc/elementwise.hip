@@ -441,7 +441,7 @@ __global__ void prefetch_kernel(const u32x4* __restrict__ p, size_t n16) {
 
 extern "C" {
 
-int vqa_abi_version(void) { return 5; }   // 5: vqa_gemm_profile_collect2 (algorithmic bytes), grouped forward / dX expert GEMMs, cross-attention block entries (round 3); 4: VQA_OPT_GRAD_BF16 job flag, vqa_prefetch, vqa_set_gemm_k_rotate / _tile_order
+int vqa_abi_version(void) { return 6; }   // 6 (round 3): VqaOptJob::touched, slotted sumsq accumulators of vqa_gemm_bf16_grouped2, vqa_set_gemm_v1_fast, the persistent-loop knobs gone; 5: vqa_gemm_profile_collect2 (algorithmic bytes), vqa_gemm_bf16_grouped2, vqa_set_gemm_dw256; 4: VQA_OPT_GRAD_BF16 job flag, vqa_prefetch, vqa_set_gemm_k_rotate / _tile_order
 int vqa_half_kind(void) { return VQA_HALF_KIND; }
 int vqa_outer_bf16(const float* x1, const float* x2, void* z_bf16, int B, int D1, int D2, vqa_stream_t s) {
     if (!x1 || !x2 || !z_bf16 || B <= 0 || D1 <= 0 || D2 <= 0 || D2 % 4) return VQA_ERR_ARG;
