@@ -1133,12 +1133,16 @@ def test_compact_prologue_ring_kernels_equal_the_general_form_bit_for_bit():
         K._k_rotate_state = None
 
 
-def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
+@pytest.mark.parametrize('half', ['bf16', 'fp16'])
+def test_specialised_epilogues_equal_the_generic_form_bit_for_bit(half):
     """The nine compile-time epilogue forms of the ring GEMM (csrc/gemm.hip: gemm_epilogue_s -- the option sets the encoders' Linear layers launch,
     scratch/gemm_census.py) against the generic run-time-flag epilogue on the same FAST loop (vqa_set_gemm_v1_fast(5)) and on the general kernel
     (0): every output stream identical to the bit (the fused bias-gradient column sums are fp32 atomics: to rounding), k rotation off and on,
-    whole and ragged row counts (1600 rows on 128-row tiles), dropout drawing the same mask."""
+    whole and ragged row counts (1600 rows on 128-row tiles), dropout drawing the same mask; in both operand types (the fp16 library is the same
+    sources compiled with another 16-bit type)."""
+    hl.set_half(half)
     L = hl.load()
+    BF = K.HALF()
     g = torch.Generator().manual_seed(11)
 
     def real(shape, s=1.0):
@@ -1150,7 +1154,8 @@ def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
              ('NT', dict(bias=1, b16=1)), ('NT', dict(f32=1)), ('NT', dict(bias=1, act=K.ACT_GELU, pre=1, drop=1, b16=1)),
              ('NN', dict(actb=K.ACT_GELU, drop=1, b16=1, colsum=1)), ('NT', dict(bias=1, f32=1))]
     try:
-        for (M, N, Kd) in [(2048, 768, 768), (1600, 768, 3072), (2048, 3072, 768), (1600, 3072, 768), (256, 64, 64), (512, 1536, 128), (128, 2048, 768), (32, 768, 2048), (72, 96, 64)]:
+        shapes = [(2048, 768, 768), (1600, 768, 3072), (2048, 3072, 768), (1600, 3072, 768), (256, 64, 64), (512, 1536, 128), (128, 2048, 768), (32, 768, 2048), (72, 96, 64)]
+        for (M, N, Kd) in (shapes if half == 'bf16' else shapes[1:4] + shapes[6:7]):
             a = real((M, Kd)).to(BF)
             w_nt = real((N, Kd), 1.0 / math.sqrt(Kd)).to(BF)
             w_nn = w_nt.t().contiguous()
@@ -1181,6 +1186,7 @@ def test_specialised_epilogues_equal_the_generic_form_bit_for_bit():
         L.vqa_set_gemm_v1_fast(1)
         L.vqa_set_gemm_k_rotate(0)
         K._k_rotate_state = None
+        hl.set_half('bf16')
 
 
 def test_fused_adamw_skips_the_moments_of_untouched_embedding_rows_exactly():

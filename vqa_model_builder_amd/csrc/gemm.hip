@@ -482,7 +482,10 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] *= act_bwd((float)pv[q][r], ACTB);
                 }
+                // (a 16-bit store takes a MATERIALISED fp32 value, as in the generic form: in the fp16 library the compiler otherwise folds the last
+                // multiply into the conversion -- v_fma_mixlo_f16, one rounding instead of two -- and the two forms differ by an ulp now and then)
                 if (PRE) {
+                    asm volatile("" : "+v"(x));
                     h16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (h16_t)x[r];
@@ -498,6 +501,7 @@ __device__ __forceinline__ void gemm_epilogue_s(const GemmArgs& p, f32x4 (&acc)[
                 if (SSQ) ssq += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
                 if (F32) *reinterpret_cast<f32x4*>(p.c_f32 + (size_t)m * p.ldc_f32 + n) = x;
                 if (B16) {
+                    asm volatile("" : "+v"(x));
                     h16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (h16_t)x[r];
