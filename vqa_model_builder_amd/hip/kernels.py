@@ -289,11 +289,12 @@ class skip_weight_grads:
         SKIP_WEIGHT_GRADS = self.prev
 
 
-def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False):
+def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=False, count_norm=True):
     """dW[N,K] = dy[M,N]^T x[M,K]  (fp32; both operands read through the transposing LDS path).  ``prezeroed``: ``out``
-    is known to be zero (gradient arena), so a split-K launch needs no memset (truthy values also keep the output out of the fused
-    clipping norm: rows of a zero-filled slot are part of a gradient nobody else writes; 2 = "not zeroed, but do not count").  With WGRAD_GROUPED (default) and a
-    caller-provided ``out`` the GEMM is only queued: the caller must end its backward with wgrad_join()."""
+    is known to be zero (a zero-filled slot of a gradient arena), so a split-K launch needs no memset.  ``count_norm=False`` (implied by
+    ``prezeroed``): the output stays out of the fused clipping norm (optim.FusedAdamW.fuse_wgrad_norm) -- rows of a zero-filled slot are part of
+    a gradient nobody else writes, and a tensor autograd will SUM with another gradient of a tied weight is no parameter's gradient at all.
+    With WGRAD_GROUPED (default) and a caller-provided ``out`` the GEMM is only queued: the caller must end its backward with wgrad_join()."""
     if SKIP_WEIGHT_GRADS and out is not None:
         return out                                      # frozen block: nobody reads this gradient
     if out is None:
@@ -302,9 +303,9 @@ def linear_dw(dy_bf16, x_bf16, M, N, K, out=None, ldy=None, ldx=None, prezeroed=
         return out
     if WGRAD_GROUPED and out.stride(-1) == 1 and N % 8 == 0 and K % 8 == 0:        # any token count M: the reduction's ragged tail is zero-filled per lane
         _, slot = _wgrad_slot()
-        slot[2].append((dy_bf16, x_bf16, M, N, K, ldy or N, ldx or K, out, prezeroed))
+        slot[2].append((dy_bf16, x_bf16, M, N, K, ldy or N, ldx or K, out, bool(prezeroed) or not count_norm))      # [8]: keep out of the fused norm
         return out
-    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=prezeroed is True or prezeroed == 1)
+    gemm(dy_bf16, x_bf16, N, K, M, ldy or N, ldx or K, False, False, out_f32=out, allow_split_k=True, c_prezeroed=bool(prezeroed))
     return out
 
 

@@ -408,9 +408,9 @@ class _LinearCEFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # through the grouped entry (the 64 000 x 768 output runs on the 256 x 256 weight-gradient tiles: 224 -> ~110 us), issued at once:
             # autograd may SUM this tensor with another gradient of a tied weight (the generative model's token embedding) as soon as it is
-            # returned -- which is also why the fused clipping norm must not count it (flag 2)
+            # returned -- which is also why the fused clipping norm must not count it
             dw = torch.empty((V, D), dtype=F32, device=xb.device)
-            K.linear_dw(dlb, xb, M, V, D, out=dw, prezeroed=2)
+            K.linear_dw(dlb, xb, M, V, D, out=dw, count_norm=False)
             K.wgrad_flush()
         return dx, dw, None, None
 
